@@ -1,0 +1,520 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle ("tier ii").  See sr_oracle.h.
+ * Each function cites the reference lines it restates.  Integer widths and
+ * wrap/truncation behaviour are the reference's (u32 wrap, s16 wrap, C99
+ * truncating division, float->u32 truncation); compile with -fwrapv.
+ */
+#include "sr_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+void cr4_fft_1024_stm32(void *pssOUT, void *pssIN, uint16_t Nbin); /* q15_fft.c */
+
+struct sr_oracle {
+    sr_oracle_cfg cfg;
+    uint32_t frame_len;    /* VAD.H:7   frame_time*fs/1000 */
+    uint32_t frame_mov;    /* VAD.H:8   frame_mov_t*fs/1000 */
+    uint32_t hop;          /* frame_len-frame_mov, the stride used everywhere */
+    uint32_t noise_len;    /* ADC.H:11  (fs/1000)*atap_len_t */
+    uint32_t atap_frm_len; /* VAD.C:13-14 (fs/1000)*30 */
+    uint32_t v_durmin_f;   /* VAD.C:72-73 80/(frame_time-frame_mov_t) */
+    uint32_t s_durmax_f;   /* VAD.C:74-75 110/(frame_time-frame_mov_t) */
+    uint32_t frq_max;      /* MFCC.H:9  nfft/2 */
+    uint16_t *hamm, *tri_cen, *tri_odd, *tri_even;
+    int8_t *dct;
+};
+
+/* Matlab int32(): round half away from zero */
+static double m_round(double v) { return v >= 0.0 ? floor(v + 0.5) : -floor(-v + 0.5); }
+
+void sr_oracle_default_cfg(sr_oracle_cfg *c)
+{
+    c->fs = 8000;
+    c->frame_time = 20;
+    c->frame_mov_t = 10;
+    c->nfft = 1024;
+    c->n_mel = 24;
+    c->n_coef = 12;
+    c->max_frames = 119;
+    c->noise_len_t = 300;
+    c->max_seg = 3;
+}
+
+/* speech_recog.m:217-222 */
+static void gen_hamm(sr_oracle *o)
+{
+    uint32_t n = o->frame_len;
+    for (uint32_t i = 0; i < n; i++) {
+        double w = 0.54 - 0.46 * cos(2 * M_PI * (double)i / (double)(n - 1));
+        o->hamm[i] = (uint16_t)m_round(w * 10000.0);
+    }
+}
+
+/* speech_recog.m:240-310.  Matlab's arrays are 1-based: element j lands at C index j-1,
+   and Matlab's tri_odd is the C table tri_even and vice versa (MFCC_Arg.h:17-27). */
+static void gen_tri(sr_oracle *o)
+{
+    const double top = 1000.0;
+    uint32_t n = o->cfg.n_mel, nb = o->frq_max;
+    double f_max = (double)o->cfg.fs / 2;
+    double mel_max = 2595 * log10(1 + f_max / 700);
+    double mel_step = mel_max / (n + 1);
+    double *cen = calloc(n + 2, sizeof(double));
+    double *m_odd = calloc(nb + 2, sizeof(double));
+    double *m_even = calloc(nb + 2, sizeof(double));
+    for (uint32_t i = 1; i <= n; i++) {
+        double c;
+        if ((double)i < 1000.0 / mel_step)
+            c = mel_step * i;
+        else
+            c = (exp(log(10) * (mel_step * i) / 2595) - 1) * 700;
+        cen[i] = m_round(c / (f_max / (double)nb));
+        o->tri_cen[i - 1] = (uint16_t)cen[i];
+    }
+#define RISE(arr, lo, hi)                                      \
+    for (long j = (long)cen[lo]; j <= (long)cen[hi]; j++)      \
+        if (j >= 1 && j <= (long)nb) arr[j] = top * (j - cen[lo]) / (cen[hi] - cen[lo]);
+#define FALL(arr, lo, hi)                                      \
+    for (long j = (long)cen[lo] + 1; j <= (long)cen[hi]; j++)  \
+        if (j >= 1 && j <= (long)nb) arr[j] = top * (cen[hi] - j) / (cen[hi] - cen[lo]);
+    for (long j = 1; j <= (long)cen[1]; j++) m_odd[j] = top * j / cen[1];
+    FALL(m_odd, 1, 2)
+    for (uint32_t h = 3; h <= n; h += 2) {
+        RISE(m_odd, h - 1, h)
+        FALL(m_odd, h, h + 1)
+    }
+    for (uint32_t h = 2; h + 2 <= n; h += 2) {
+        RISE(m_even, h - 1, h)
+        FALL(m_even, h, h + 1)
+    }
+    RISE(m_even, n - 1, n)
+    for (long j = (long)cen[n] + 1; j <= (long)nb; j++) m_even[j] = top * ((double)nb - j) / ((double)nb - cen[n]);
+#undef RISE
+#undef FALL
+    for (uint32_t j = 1; j <= nb; j++) {
+        o->tri_even[j - 1] = (uint16_t)m_round(m_odd[j]);
+        o->tri_odd[j - 1] = (uint16_t)m_round(m_even[j]);
+    }
+    free(cen);
+    free(m_odd);
+    free(m_even);
+}
+
+/* teat.m:19-26 */
+static void gen_dct(sr_oracle *o)
+{
+    uint32_t nm = o->cfg.n_mel, nc = o->cfg.n_coef;
+    for (uint32_t h = 1; h <= nc; h++)
+        for (uint32_t j = 1; j <= nm; j++)
+            o->dct[(h - 1) * nm + (j - 1)] = (int8_t)m_round(cos(h * M_PI * (j - 0.5) / nm) * 100);
+}
+
+sr_oracle *sr_oracle_create(const sr_oracle_cfg *cfg)
+{
+    sr_oracle *o;
+    if (cfg->nfft != 1024 || (cfg->n_mel & 1) || cfg->n_mel < 4 || cfg->max_frames == 0 || cfg->max_frames > 16383)
+        return NULL;
+    o = calloc(1, sizeof(*o));
+    o->cfg = *cfg;
+    o->frame_len = cfg->frame_time * cfg->fs / 1000;
+    o->frame_mov = cfg->frame_mov_t * cfg->fs / 1000;
+    o->hop = o->frame_len - o->frame_mov;
+    o->noise_len = (cfg->fs / 1000) * cfg->noise_len_t;
+    o->atap_frm_len = (cfg->fs / 1000) * 30;
+    o->v_durmin_f = 80 / (cfg->frame_time - cfg->frame_mov_t);
+    o->s_durmax_f = 110 / (cfg->frame_time - cfg->frame_mov_t);
+    o->frq_max = cfg->nfft / 2;
+    if (o->frame_len > cfg->nfft || o->frame_len < 2) {
+        free(o);
+        return NULL;
+    }
+    o->hamm = calloc(o->frame_len, sizeof(uint16_t));
+    o->tri_cen = calloc(cfg->n_mel, sizeof(uint16_t));
+    o->tri_odd = calloc(o->frq_max, sizeof(uint16_t));
+    o->tri_even = calloc(o->frq_max, sizeof(uint16_t));
+    o->dct = calloc(cfg->n_coef * cfg->n_mel, 1);
+    gen_hamm(o);
+    gen_tri(o);
+    gen_dct(o);
+    return o;
+}
+
+void sr_oracle_destroy(sr_oracle *o)
+{
+    if (!o)
+        return;
+    free(o->hamm);
+    free(o->tri_cen);
+    free(o->tri_odd);
+    free(o->tri_even);
+    free(o->dct);
+    free(o);
+}
+
+uint32_t sr_oracle_frame_len(const sr_oracle *o) { return o->frame_len; }
+uint32_t sr_oracle_hop(const sr_oracle *o) { return o->hop; }
+uint32_t sr_oracle_noise_len(const sr_oracle *o) { return o->noise_len; }
+const uint16_t *sr_oracle_hamm(const sr_oracle *o) { return o->hamm; }
+const uint16_t *sr_oracle_tri_cen(const sr_oracle *o) { return o->tri_cen; }
+const uint16_t *sr_oracle_tri_odd(const sr_oracle *o) { return o->tri_odd; }
+const uint16_t *sr_oracle_tri_even(const sr_oracle *o) { return o->tri_even; }
+const int8_t *sr_oracle_dct(const sr_oracle *o) { return o->dct; }
+
+/* ---- VAD.C:22-71 -------------------------------------------------------- */
+int sr_oracle_noise_atap(const sr_oracle *o, const uint16_t *noise, uint32_t n_len, sr_oracle_atap *atap)
+{
+    uint32_t afl = o->atap_frm_len;
+    uint32_t n_sum = 0, max_sum = 0, abs_sum = 0, mid;
+    if (n_len == 0 || (n_len % afl) != 0)
+        return 1; /* VAD.C:33-36: silent return, atap left as it was */
+    for (uint32_t i = 0; i < n_len; i++) n_sum += noise[i];
+    mid = n_sum / n_len;
+    for (uint32_t i = 0; i < n_len; i += afl) {
+        uint32_t n_max = 0;
+        for (uint32_t h = 0; h < afl; h++) {
+            uint32_t v = noise[i + h];
+            uint32_t a = (v > mid) ? (v - mid) : (mid - v);
+            if (a > n_max)
+                n_max = a;
+            abs_sum += a;
+        }
+        max_sum += n_max;
+    }
+    abs_sum /= (n_len / o->frame_len); /* VAD.C:65: divisor counts frame_len blocks, not atap frames */
+    max_sum /= (n_len / afl);
+    atap->mid_val = mid;
+    atap->n_thl = (uint16_t)(max_sum * 1);      /* n_thl_ratio 1 */
+    atap->s_thl = abs_sum * 11 / 10;            /* s_thl_ratio 11/10 */
+    atap->z_thl = (uint16_t)(o->frame_len * 2 / 160 / 1); /* VAD.C:70 with z_thl_ratio 2/160 */
+    return 0;
+}
+
+/* ---- VAD.C:97-218 ------------------------------------------------------- */
+void sr_oracle_vad(const sr_oracle *o, const uint16_t *vc, uint32_t buf_len, const sr_oracle_atap *atap, int32_t *seg)
+{
+    uint8_t last_sig = 0; /* never reset: carries across samples AND frames (VAD.C:99) */
+    uint8_t cur_stus = 0;
+    uint32_t front = 0, back = 0, valid_con = 0;
+    uint32_t fl = o->frame_len, hop = o->hop;
+    uint32_t mid = atap->mid_val;
+    uint32_t a_thl = mid + atap->n_thl;
+    uint32_t b_thl = mid - atap->n_thl; /* wraps if n_thl > mid, as in the reference */
+
+    for (uint32_t s = 0; s < o->cfg.max_seg; s++) seg[2 * s] = seg[2 * s + 1] = -1;
+    if (buf_len < fl)
+        return;
+    for (uint32_t i = 0; i < buf_len - fl; i += hop) {
+        uint32_t frm_sum = 0, frm_zero = 0;
+        for (uint32_t h = 0; h < fl; h++) {
+            uint32_t v = vc[i + h];
+            frm_sum += (v > mid) ? (v - mid) : (mid - v);
+        }
+        for (uint32_t h = 0; h < fl - 1; h++) {
+            uint32_t v0 = vc[i + h], v1 = vc[i + h + 1];
+            if (v0 >= a_thl)
+                last_sig = 2;
+            else if (v0 < b_thl)
+                last_sig = 1;
+            if (v1 >= a_thl) {
+                if (last_sig == 1)
+                    frm_zero++;
+            } else if (v1 < b_thl) {
+                if (last_sig == 2)
+                    frm_zero++;
+            }
+        }
+        if (frm_sum > atap->s_thl || frm_zero > atap->z_thl) {
+            if (cur_stus == 0) {
+                cur_stus = 1;
+                front = 1;
+            } else if (cur_stus == 1) {
+                front++;
+                if (front >= o->v_durmin_f) {
+                    cur_stus = 2;
+                    seg[2 * valid_con] = (int32_t)i - (int32_t)((o->v_durmin_f - 1) * hop);
+                    front = 0;
+                }
+            } else if (cur_stus == 3) {
+                back = 0;
+                cur_stus = 2;
+            }
+        } else {
+            if (cur_stus == 2) {
+                cur_stus = 3;
+                back = 1;
+            } else if (cur_stus == 3) {
+                back++;
+                if (back >= o->s_durmax_f) {
+                    cur_stus = 0;
+                    seg[2 * valid_con + 1] = (int32_t)i - (int32_t)(o->s_durmax_f * hop) + (int32_t)fl;
+                    valid_con++;
+                    if (valid_con == o->cfg.max_seg)
+                        return;
+                    back = 0;
+                }
+            } else if (cur_stus == 1) {
+                front = 0;
+                cur_stus = 0;
+            }
+        }
+    }
+}
+
+/* ---- MFCC.C:27-62 ------------------------------------------------------- */
+int sr_oracle_fft_mag(const sr_oracle *o, const int16_t *frame, uint32_t len, uint32_t *mag)
+{
+    uint32_t in[1024], out[1024];
+    if (len > o->cfg.nfft)
+        return 1;
+    for (uint32_t i = 0; i < len; i++) in[i] = (uint16_t)frame[i]; /* imag = 0 in the high half */
+    for (uint32_t i = len; i < o->cfg.nfft; i++) in[i] = 0;
+    cr4_fft_1024_stm32(out, in, (uint16_t)o->cfg.nfft);
+    for (uint32_t i = 0; i < o->frq_max; i++) {
+        int32_t re = (int16_t)out[i], im = (int16_t)(out[i] >> 16);
+        int32_t r = re * re + im * im;
+        mag[i] = (uint32_t)(sqrtf((float)r) * 10);
+    }
+    return 0;
+}
+
+/* one frame of MFCC.C:113-187; x points at the frame's first sample, x[-1] is read */
+static void mfcc_frame(const sr_oracle *o, const uint16_t *x, int32_t mid, int16_t *out)
+{
+    int16_t vc_temp[1024];
+    uint32_t spct[512];
+    uint32_t pw[64];
+    const uint16_t *cen = o->tri_cen;
+    uint32_t fl = o->frame_len, nb = o->frq_max, nm = o->cfg.n_mel, nc = o->cfg.n_coef;
+
+    for (uint32_t i = 0; i < fl; i++) {
+        /* MFCC.C:119: (x[i]-mid) - (x[i-1]-mid)*95/100, * then / left to right, truncating */
+        int32_t t = ((int32_t)x[i] - mid) - ((int32_t)x[(int32_t)i - 1] - mid) * 95 / 100;
+        vc_temp[i] = (int16_t)(t * (int32_t)o->hamm[i] / (10000 / 10)); /* MFCC.C:122 */
+    }
+    sr_oracle_fft_mag(o, vc_temp, fl, spct);
+    for (uint32_t i = 0; i < nb; i++) spct[i] *= spct[i]; /* MFCC.C:131, u32 wrap */
+
+    /* MFCC.C:136-162: each term divided by tri_top/10 = 100 before accumulation, u32 wrap */
+    pw[0] = 0;
+    for (uint32_t i = 0; i < cen[1]; i++) pw[0] += spct[i] * o->tri_even[i] / 100;
+    for (uint32_t h = 2; h < nm; h += 2) {
+        pw[h] = 0;
+        for (uint32_t i = cen[h - 1]; i < cen[h + 1]; i++) pw[h] += spct[i] * o->tri_even[i] / 100;
+    }
+    for (uint32_t h = 1; h < nm - 2; h += 2) {
+        pw[h] = 0;
+        for (uint32_t i = cen[h - 1]; i < cen[h + 1]; i++) pw[h] += spct[i] * o->tri_odd[i] / 100;
+    }
+    pw[nm - 1] = 0;
+    for (uint32_t i = cen[nm - 2]; i < nb; i++) pw[nm - 1] += spct[i] * o->tri_odd[i] / 100;
+
+    /* MFCC.C:165-170.  log(0) = -inf; (u32)(-inf) is UB in C but yields 0 on ARM softfp
+       and on x86-64 gcc; made explicit here. */
+    for (uint32_t h = 0; h < nm; h++) pw[h] = pw[h] ? (uint32_t)(log((double)pw[h]) * 100) : 0u;
+
+    /* MFCC.C:173-183: per-term truncating /100, accumulated in s16 */
+    for (uint32_t h = 0; h < nc; h++) {
+        int16_t acc = 0;
+        for (uint32_t i = 0; i < nm; i++) acc += (int16_t)((int32_t)pw[i] * (int32_t)o->dct[h * nm + i] / 100);
+        out[h] = acc;
+    }
+}
+
+/* ---- MFCC.C:86-191 ------------------------------------------------------ */
+uint32_t sr_oracle_mfcc(const sr_oracle *o, const uint16_t *buf, int32_t start, int32_t end,
+                        const sr_oracle_atap *atap, int16_t *mfcc)
+{
+    uint32_t fl = o->frame_len, hop = o->hop;
+    /* MFCC.C:102, u32 arithmetic then truncated to u16 */
+    uint16_t n = (uint16_t)(((uint32_t)(end - start) - fl) / hop + 1);
+    uint32_t cnt = 0;
+    if (n > o->cfg.max_frames)
+        return 0; /* MFCC.C:103-107 */
+    for (int32_t p = start; p <= end - (int32_t)fl; p += (int32_t)hop) {
+        mfcc_frame(o, buf + p, (int32_t)atap->mid_val, mfcc + (size_t)cnt * o->cfg.n_coef);
+        cnt++;
+    }
+    return cnt;
+}
+
+/* ---- DTW.C:45-62 -------------------------------------------------------- */
+uint32_t sr_oracle_get_dis(const int16_t *a, const int16_t *b, uint32_t n_coef)
+{
+    uint32_t dis = 0;
+    for (uint32_t i = 0; i < n_coef; i++) {
+        int32_t d = (int32_t)a[i] - (int32_t)b[i];
+        dis += (uint32_t)d * (uint32_t)d;
+    }
+    return (uint32_t)sqrtf((float)dis);
+}
+
+/* ---- DTW.C:76-109 (file statics become arguments) ----------------------- */
+static int dtw_outside(int x, int y, int X1, int X2, int in_n, int mdl_n)
+{
+    if (x < X1) {
+        if (y >= 2 * x + 2)
+            return 1;
+    } else {
+        if (2 * y + in_n - 2 * mdl_n >= x + 4)
+            return 1;
+    }
+    if (x < X2) {
+        if (2 * y + 2 <= x)
+            return 1;
+    } else {
+        if (y + 4 <= 2 * x + mdl_n - 2 * in_n)
+            return 1;
+    }
+    return 0;
+}
+
+/* ---- DTW.C:120-192: greedy local walk, tie order diagonal > up > right -- */
+uint32_t sr_oracle_dtw(const int16_t *in, uint32_t in_n, const int16_t *mdl, uint32_t mdl_n, uint32_t nc)
+{
+    uint32_t dis, step, x, y;
+    int X1, X2;
+    if (in_n > mdl_n * 2 || 2 * in_n < mdl_n)
+        return SR_ORACLE_DIS_ERR;
+    X1 = (int)(uint16_t)((2 * (int)mdl_n - (int)in_n) / 3);
+    X2 = (int)(uint16_t)((4 * (int)in_n - 2 * (int)mdl_n) / 3);
+    dis = sr_oracle_get_dis(in, mdl, nc);
+    x = y = step = 1;
+    do {
+        uint32_t up, right, diag, mn;
+        up = dtw_outside((int)x, (int)y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_ORACLE_DIS_ERR
+                                                                             : sr_oracle_get_dis(mdl + nc, in, nc);
+        right = dtw_outside((int)x + 1, (int)y, X1, X2, (int)in_n, (int)mdl_n) ? SR_ORACLE_DIS_ERR
+                                                                                : sr_oracle_get_dis(mdl, in + nc, nc);
+        diag = dtw_outside((int)x + 1, (int)y + 1, X1, X2, (int)in_n, (int)mdl_n)
+                   ? SR_ORACLE_DIS_ERR
+                   : sr_oracle_get_dis(mdl + nc, in + nc, nc);
+        mn = diag;
+        if (mn > right)
+            mn = right;
+        if (mn > up)
+            mn = up;
+        dis += mn; /* u32 wrap when all three are dis_err */
+        if (mn == diag) {
+            in += nc;
+            x++;
+            mdl += nc;
+            y++;
+        } else if (mn == up) {
+            mdl += nc;
+            y++;
+        } else {
+            in += nc;
+            x++;
+        }
+        step = (uint16_t)(step + 1);
+    } while (x < in_n && y < mdl_n);
+    return dis / step;
+}
+
+/* ---- main.c:249-296 ----------------------------------------------------- */
+void sr_oracle_recognize(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len, const sr_oracle_templates *tpl,
+                         sr_oracle_result *res, int16_t *mfcc_out, uint32_t *scores)
+{
+    sr_oracle_atap atap;
+    int32_t seg[16];
+    int16_t *mfcc = mfcc_out;
+    uint32_t nfrm, min_dis = SR_ORACLE_DIS_ERR, min_idx = 0;
+    uint32_t nc = o->cfg.n_coef;
+
+    memset(&atap, 0, sizeof atap);
+    res->best_tpl = 0;
+    res->min_dis = SR_ORACLE_DIS_ERR;
+    res->frm_num = 0;
+    if (scores)
+        for (uint32_t k = 0; k < tpl->n; k++) scores[k] = SR_ORACLE_DIS_ERR;
+    sr_oracle_noise_atap(o, pcm, o->noise_len, &atap);
+    sr_oracle_vad(o, pcm, buf_len, &atap, seg);
+    if (seg[1] < 0) {
+        res->status = SR_ORACLE_VAD_FAIL;
+        return;
+    }
+    if (seg[0] < 1) {
+        res->status = SR_ORACLE_SEG_OOB;
+        return;
+    }
+    if (!mfcc)
+        mfcc = malloc(sizeof(int16_t) * (size_t)(o->cfg.max_frames + 1) * nc);
+    nfrm = sr_oracle_mfcc(o, pcm, seg[0], seg[1], &atap, mfcc);
+    res->frm_num = nfrm;
+    if (nfrm == 0) {
+        res->status = SR_ORACLE_MFCC_FAIL;
+    } else {
+        for (uint32_t k = 0; k < tpl->n; k++) {
+            uint32_t cur = tpl->valid[k] ? sr_oracle_dtw(mfcc, nfrm, tpl->mfcc + (size_t)k * tpl->stride, tpl->frames[k], nc)
+                                         : SR_ORACLE_DIS_ERR;
+            if (scores)
+                scores[k] = cur;
+            if (cur < min_dis) {
+                min_dis = cur;
+                min_idx = k;
+            }
+        }
+        res->best_tpl = min_idx;
+        res->min_dis = min_dis;
+        res->status = SR_ORACLE_OK;
+    }
+    if (!mfcc_out)
+        free(mfcc);
+}
+
+typedef struct {
+    const sr_oracle *o;
+    const uint16_t *pcm;
+    uint64_t pcm_stride;
+    uint32_t buf_len, b0, b1;
+    const sr_oracle_templates *tpl;
+    sr_oracle_result *res;
+    int16_t *mfcc_out;
+    uint32_t *scores;
+} batch_job;
+
+static void *batch_worker(void *arg)
+{
+    batch_job *j = arg;
+    size_t msz = (size_t)j->o->cfg.max_frames * j->o->cfg.n_coef;
+    for (uint32_t b = j->b0; b < j->b1; b++)
+        sr_oracle_recognize(j->o, j->pcm + (size_t)b * j->pcm_stride, j->buf_len, j->tpl, &j->res[b],
+                            j->mfcc_out ? j->mfcc_out + (size_t)b * msz : NULL,
+                            j->scores ? j->scores + (size_t)b * j->tpl->n : NULL);
+    return NULL;
+}
+
+void sr_oracle_recognize_batch(const sr_oracle *o, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len,
+                               uint32_t B, const sr_oracle_templates *tpl, sr_oracle_result *res, int16_t *mfcc_out,
+                               uint32_t *scores, uint32_t n_threads)
+{
+    pthread_t th[256];
+    batch_job jobs[256];
+    if (n_threads < 1)
+        n_threads = 1;
+    if (n_threads > 256)
+        n_threads = 256;
+    if (n_threads > B)
+        n_threads = B ? B : 1;
+    for (uint32_t t = 0; t < n_threads; t++) {
+        batch_job *j = &jobs[t];
+        j->o = o;
+        j->pcm = pcm;
+        j->pcm_stride = pcm_stride;
+        j->buf_len = buf_len;
+        j->b0 = (uint32_t)((uint64_t)B * t / n_threads);
+        j->b1 = (uint32_t)((uint64_t)B * (t + 1) / n_threads);
+        j->tpl = tpl;
+        j->res = res;
+        j->mfcc_out = mfcc_out;
+        j->scores = scores;
+        if (n_threads == 1)
+            batch_worker(j);
+        else
+            pthread_create(&th[t], NULL, batch_worker, j);
+    }
+    if (n_threads > 1)
+        for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+}

@@ -1,0 +1,134 @@
+"""Generate tests/golden/ref_golden.npz from TIER (i) of the oracle, i.e. from the
+reference's own VAD.C / MFCC.C / DTW.C objects (oracle/_ref/libsr_ref.so).
+
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+The reference ships no golden vectors of its own; these fixtures are
+what pins parity on the GPU box, where /root/reference does not exist.
+
+Inputs are synthetic (seeded) or random; nothing is copied from the reference tree.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle_lib as ol  # noqa: E402
+from stm32_speech_recognition_amd import synth  # noqa: E402
+
+
+def main():
+    r = ol.RefLib()
+    rng = np.random.default_rng(20260925)
+    g = {}
+
+    # --- FFT: random packed complex inputs, incl. full-scale and a zero-padded real frame
+    fin = np.zeros((24, 1024), dtype=np.uint32)
+    for i in range(24):
+        amp = [50, 500, 5000, 32767][i % 4]
+        re = rng.integers(-amp, amp + 1, 1024).astype(np.int16)
+        im = rng.integers(-amp, amp + 1, 1024).astype(np.int16)
+        if i >= 16:  # the shape get_mfcc feeds: 160 real samples, rest zero
+            re[160:] = 0
+            im[:] = 0
+        fin[i] = re.view(np.uint16).astype(np.uint32) | (im.view(np.uint16).astype(np.uint32) << 16)
+    g["fft_in"] = fin
+    g["fft_out"] = np.stack([r.fft(w) for w in fin])
+
+    # --- whole path on synthetic captures (T <= 119 so the verbatim objects can run them)
+    bank = synth.word_bank(10)
+    B = 12
+    frames = np.array([100, 64, 119, 30, 80, 119, 90, 50, 110, 75, 118, 40])
+    words = np.arange(B) % 10
+    gains = [1.0] * 8 + [6.0, 6.0, 0.05, 0.02]  # loud (u32 wrap in the filterbank) and near-silent rows
+    pcm = np.zeros((B, 16000), dtype=np.uint16)
+    for b in range(B):
+        x = synth.make_utterances([words[b]], [frames[b]], seed=100 + b, bank=bank, S=16000, gain=gains[b],
+                                  quiet_sigma=8.0 if b % 3 == 0 else 4.0)
+        pcm[b] = synth.as_u16_numpy(x)[0]
+    g["pcm"] = pcm
+    atap = np.zeros((B, 4), dtype=np.uint32)
+    seg = np.zeros((B, 6), dtype=np.int32)
+    nfrm = np.zeros(B, dtype=np.uint32)
+    mfcc = np.zeros((B, 119, 12), dtype=np.int16)
+    for b in range(B):
+        a, s = r.vad(pcm[b])
+        atap[b] = a.astuple()
+        seg[b] = s
+        if s[1] >= 0 and s[0] >= 1:
+            n, m, _ = r.mfcc(pcm[b], s[0], s[1], a)
+            nfrm[b] = n
+            mfcc[b, :n] = m
+    g["atap"], g["seg"], g["frm_num"], g["mfcc"] = atap, seg, nfrm, mfcc
+
+
+    # --- get_mfcc on crafted segments: all-zero frames (filterbank 0 -> log(0)), full-scale
+    #     Nyquist square wave (s16 wrap at MFCC.C:122), random 12-bit and random full-u16 codes
+    D = 4
+    nfd = 20
+    Sd = 1 + 160 + 80 * (nfd - 1) + 7
+    dp = np.zeros((D, Sd), dtype=np.uint16)
+    dp[0, :] = 2048
+    dp[1, :] = np.where(np.arange(Sd) % 2 == 0, 0, 4095)
+    dp[2, :] = rng.integers(0, 4096, Sd)
+    dp[3, :] = rng.integers(0, 65536, Sd)
+    dmid = np.array([2048, 2047, 2040, 30000], dtype=np.uint32)
+    dm = np.zeros((D, nfd, 12), dtype=np.int16)
+    for d in range(D):
+        a = ol.Atap(int(dmid[d]), 10, 2, 1000)
+        n, m, _ = r.mfcc(dp[d], 1, 1 + 160 + 80 * (nfd - 1), a)
+        assert n == nfd
+        dm[d] = m
+    g["direct_pcm"], g["direct_mid"], g["direct_mfcc"] = dp, dmid, dm
+
+    # --- template store in the firmware's flash layout (Flash.H:11-20): 4 KiB slots, save_mask 12345
+    K = 20
+    store = np.zeros(K * 4096, dtype=np.uint8)
+    tfr = np.array([60, 100, 119, 45, 80, 70, 119, 30, 90, 110, 20, 100, 64, 119, 55, 75, 85, 95, 105, 115])
+    for k in range(K):
+        x = synth.as_u16_numpy(synth.make_utterances([k % 10], [tfr[k]], seed=500 + k, bank=bank, S=16000))[0]
+        a, s = r.vad(x)
+        n, m, ftr = r.mfcc(x, s[0], s[1], a)
+        assert n == tfr[k], (k, n, tfr[k])
+        if k == 7:
+            ftr.view(np.uint16)[0] = 0  # an erased slot: save_sign != 12345 -> dis_err (main.c:283)
+        store[k * 4096:k * 4096 + len(ftr)] = ftr
+    g["store"] = store
+    st = np.zeros(B, dtype=np.uint32)
+    best = np.zeros(B, dtype=np.uint32)
+    dis = np.zeros(B, dtype=np.uint32)
+    scores = np.zeros((B, K), dtype=np.uint32)
+    for b in range(B):
+        st[b], best[b], dis[b], scores[b], _, _ = r.spch_recg(pcm[b], store)
+    g["recg_status"], g["recg_best"], g["recg_dis"], g["recg_scores"] = st, best, dis, scores
+
+    # --- DTW on random feature pairs: all length gates, 1-frame inputs, extreme coefficients
+    P = 400
+    dl = np.zeros((P, 2), dtype=np.uint32)
+    da = np.zeros((P, 119, 12), dtype=np.int16)
+    db = np.zeros((P, 119, 12), dtype=np.int16)
+    dd = np.zeros(P, dtype=np.uint32)
+    for p in range(P):
+        na, nb = rng.integers(1, 120, 2)
+        if p % 5 == 0:
+            nb = min(119, max(1, int(na * rng.uniform(0.45, 2.2))))
+        amp = [300, 2000, 32767][p % 3]
+        a = rng.integers(-amp, amp + 1, (119, 12)).astype(np.int16)
+        bb = (a + rng.integers(-amp // 4, amp // 4 + 1, (119, 12))).clip(-32768, 32767).astype(np.int16) \
+            if p % 2 else rng.integers(-amp, amp + 1, (119, 12)).astype(np.int16)
+        dl[p] = (na, nb)
+        da[p], db[p] = a, bb
+        dd[p] = r.dtw(ol.RefLib.make_ftr(a, na), ol.RefLib.make_ftr(bb, nb))
+    g["dtw_len"], g["dtw_a"], g["dtw_b"], g["dtw_dis"] = dl, da, db, dd
+
+    out = os.path.join(HERE, "ref_golden.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, os.path.getsize(out), "bytes;",
+          "status", st.tolist(), "frm", nfrm.tolist(), "dtw err", int((dd == 0xFFFFFFFF).sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,235 @@
+"""ctypes bindings for the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module.  The product package never does.
+
+  Oracle  -- tier (ii): oracle/liboracle.so, own parametrised restatement
+  RefLib  -- tier (i):  oracle/_ref/libsr_ref.so, the reference's own VAD.C /
+             MFCC.C / DTW.C compiled verbatim (+ C transcription of the asm FFT)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_PATH = os.path.join(ORACLE_DIR, "_ref", "libsr_ref.so")
+
+DIS_ERR = 0xFFFFFFFF
+ST_OK, ST_VAD_FAIL, ST_MFCC_FAIL, ST_SEG_OOB = 0, 1, 2, 3
+
+
+def build(force=False):
+    """(Re)build the oracle libraries with oracle/Makefile (gcc only, seconds)."""
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sr_oracle.c", "sr_oracle.h", "q15_fft.c", "ref_glue.c", "Makefile")]
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
+    if os.path.isdir("/root/reference/Src/Speech_Recog") and not os.path.exists(REF_PATH):
+        stale = True
+    if stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "all"], stdout=subprocess.DEVNULL)
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("fs", "frame_time", "frame_mov_t", "nfft", "n_mel", "n_coef",
+                                          "max_frames", "noise_len_t", "max_seg")]
+
+
+class Atap(C.Structure):
+    _fields_ = [("mid_val", C.c_uint32), ("n_thl", C.c_uint16), ("z_thl", C.c_uint16), ("s_thl", C.c_uint32)]
+
+    def astuple(self):
+        return (self.mid_val, self.n_thl, self.z_thl, self.s_thl)
+
+
+class Templates(C.Structure):
+    _fields_ = [("mfcc", C.c_void_p), ("frames", C.c_void_p), ("valid", C.c_void_p),
+                ("n", C.c_uint32), ("stride", C.c_uint32)]
+
+
+RESULT_DTYPE = np.dtype([("best_tpl", "<u4"), ("min_dis", "<u4"), ("frm_num", "<u4"), ("status", "<u4")])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, max_frames=119, **kw):
+        build()
+        L = C.CDLL(LIB_PATH)
+        self.L = L
+        cfg = Cfg()
+        L.sr_oracle_default_cfg(C.byref(cfg))
+        cfg.max_frames = max_frames
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        L.sr_oracle_create.restype = C.c_void_p
+        self.h = L.sr_oracle_create(C.byref(cfg))
+        if not self.h:
+            raise ValueError("unsupported oracle config")
+        self.h = C.c_void_p(self.h)
+        for f in ("frame_len", "hop", "noise_len"):
+            getattr(L, "sr_oracle_" + f).restype = C.c_uint32
+            getattr(L, "sr_oracle_" + f).argtypes = [C.c_void_p]
+        self.frame_len = L.sr_oracle_frame_len(self.h)
+        self.hop = L.sr_oracle_hop(self.h)
+        self.noise_len = L.sr_oracle_noise_len(self.h)
+        self.n_coef = cfg.n_coef
+        self.n_mel = cfg.n_mel
+        self.max_frames = cfg.max_frames
+        L.sr_oracle_get_dis.restype = C.c_uint32
+        L.sr_oracle_dtw.restype = C.c_uint32
+        L.sr_oracle_mfcc.restype = C.c_uint32
+
+    def __del__(self):
+        try:
+            self.L.sr_oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def _tab(self, name, n, dt):
+        f = getattr(self.L, "sr_oracle_" + name)
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p]
+        return np.ctypeslib.as_array(C.cast(f(self.h), C.POINTER(dt)), shape=(n,)).copy()
+
+    def tables(self):
+        nb = self.cfg.nfft // 2
+        return dict(hamm=self._tab("hamm", self.frame_len, C.c_uint16),
+                    tri_cen=self._tab("tri_cen", self.n_mel, C.c_uint16),
+                    tri_odd=self._tab("tri_odd", nb, C.c_uint16),
+                    tri_even=self._tab("tri_even", nb, C.c_uint16),
+                    dct=self._tab("dct", self.n_coef * self.n_mel, C.c_int8))
+
+    def noise_atap(self, pcm, n_len=None):
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        a = Atap()
+        rc = self.L.sr_oracle_noise_atap(self.h, _p(pcm), C.c_uint32(self.noise_len if n_len is None else n_len),
+                                         C.byref(a))
+        return rc, a
+
+    def vad(self, pcm, atap):
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        seg = np.full(2 * self.cfg.max_seg, -1, dtype=np.int32)
+        self.L.sr_oracle_vad(self.h, _p(pcm), C.c_uint32(len(pcm)), C.byref(atap), _p(seg))
+        return seg
+
+    def fft_mag(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.int16)
+        mag = np.zeros(self.cfg.nfft // 2, dtype=np.uint32)
+        self.L.sr_oracle_fft_mag(self.h, _p(frame), C.c_uint32(len(frame)), _p(mag))
+        return mag
+
+    def mfcc(self, pcm, start, end, atap):
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        out = np.zeros((self.max_frames + 1, self.n_coef), dtype=np.int16)
+        n = self.L.sr_oracle_mfcc(self.h, _p(pcm), C.c_int32(start), C.c_int32(end), C.byref(atap), _p(out))
+        return n, out[:n].copy()
+
+    def get_dis(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.int16)
+        b = np.ascontiguousarray(b, dtype=np.int16)
+        return self.L.sr_oracle_get_dis(_p(a), _p(b), C.c_uint32(len(a)))
+
+    def dtw(self, a, na, b, nb):
+        """a, b: int16 arrays [>=n+1 frames, n_coef] (one frame of slack is read by the do-while)."""
+        a = np.ascontiguousarray(a, dtype=np.int16)
+        b = np.ascontiguousarray(b, dtype=np.int16)
+        return self.L.sr_oracle_dtw(_p(a), C.c_uint32(na), _p(b), C.c_uint32(nb), C.c_uint32(self.n_coef))
+
+    def make_templates(self, tpl_mfcc, tpl_frames, tpl_valid=None):
+        """tpl_mfcc: int16 [K, Tt, n_coef] (Tt >= max frames + 1)."""
+        tpl_mfcc = np.ascontiguousarray(tpl_mfcc, dtype=np.int16)
+        tpl_frames = np.ascontiguousarray(tpl_frames, dtype=np.uint32)
+        K = tpl_mfcc.shape[0]
+        if tpl_valid is None:
+            tpl_valid = np.ones(K, dtype=np.uint8)
+        tpl_valid = np.ascontiguousarray(tpl_valid, dtype=np.uint8)
+        t = Templates(_p(tpl_mfcc).value, _p(tpl_frames).value, _p(tpl_valid).value, K,
+                      tpl_mfcc.shape[1] * tpl_mfcc.shape[2])
+        t._keep = (tpl_mfcc, tpl_frames, tpl_valid)
+        return t
+
+    def recognize_batch(self, pcm, tpl, n_threads=1, want_mfcc=True, want_scores=True):
+        """pcm: uint16 [B, S].  Returns (results[B], mfcc[B, max_frames, C] | None, scores[B, K] | None)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        B, S = pcm.shape
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        mf = np.zeros((B, self.max_frames, self.n_coef), dtype=np.int16) if want_mfcc else None
+        sc = np.zeros((B, tpl.n), dtype=np.uint32) if want_scores else None
+        self.L.sr_oracle_recognize_batch(self.h, _p(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B), C.byref(tpl),
+                                         _p(res), _p(mf) if want_mfcc else None, _p(sc) if want_scores else None,
+                                         C.c_uint32(n_threads))
+        return res, mf, sc
+
+
+class RefLib:
+    """Tier (i): the reference's own objects.  Non-reentrant (file-scope statics): single thread only."""
+    FTR_BYTES = 2860  # sizeof(v_ftr_tag) at vv_frm_max = 119 (MFCC.H:18-25)
+
+    @staticmethod
+    def available():
+        build()
+        return os.path.exists(REF_PATH)
+
+    def __init__(self):
+        build()
+        self.L = C.CDLL(REF_PATH)
+        self.L.dtw.restype = C.c_uint32
+        self.L.get_dis.restype = C.c_uint32
+        self.L.dtw_limit.restype = C.c_uint8
+        assert self.L.sr_ref_sizeof_ftr() == self.FTR_BYTES
+
+    def vad(self, pcm, noise_len=2400):
+        """pcm: uint16 [S]; returns (Atap, seg[6])."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        a = Atap()
+        seg = np.zeros(6, dtype=np.int32)
+        self.L.sr_ref_vad(_p(pcm), C.c_uint16(len(pcm)), C.c_uint16(noise_len), C.byref(a), _p(seg))
+        return a, seg
+
+    def mfcc(self, pcm, start, end, atap):
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        ftr = np.zeros(self.FTR_BYTES, dtype=np.uint8)
+        self.L.sr_ref_mfcc(_p(pcm), C.c_int32(start), C.c_int32(end), C.byref(atap), _p(ftr))
+        h = ftr.view(np.int16)
+        n = int(ftr.view(np.uint16)[1])
+        return n, h[2:2 + n * 12].reshape(n, 12).copy(), ftr
+
+    def fft(self, words):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        out = np.zeros(1024, dtype=np.uint32)
+        self.L.cr4_fft_1024_stm32(_p(out), _p(words), C.c_uint16(1024))
+        return out
+
+    @staticmethod
+    def make_ftr(mfcc, n, save_sign=12345):
+        """Pack [n,12] int16 into a v_ftr_tag image (MFCC.H:18-25)."""
+        ftr = np.zeros(RefLib.FTR_BYTES, dtype=np.uint8)
+        ftr.view(np.uint16)[0] = save_sign
+        ftr.view(np.uint16)[1] = n
+        m = np.ascontiguousarray(mfcc, dtype=np.int16).reshape(-1)
+        ftr.view(np.int16)[2:2 + len(m)] = m[:119 * 12]
+        return ftr
+
+    def dtw(self, ftr_in, ftr_mdl):
+        return self.L.dtw(_p(ftr_in), _p(ftr_mdl))
+
+    def spch_recg(self, pcm, store, stride=4096, noise_len=2400):
+        """store: uint8 [n_slots*stride] flash-style image.  Returns (status, best_slot, dis, scores, mfcc, n)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        n_slots = len(store) // stride
+        ftr = np.zeros(self.FTR_BYTES, dtype=np.uint8)
+        best = C.c_uint32(0)
+        dis = C.c_uint32(0)
+        scores = np.zeros(n_slots, dtype=np.uint32)
+        st = self.L.sr_ref_spch_recg(_p(pcm), C.c_uint16(len(pcm)), C.c_uint16(noise_len), _p(store),
+                                     C.c_uint32(n_slots), C.c_uint32(stride), _p(ftr), C.byref(best), C.byref(dis),
+                                     _p(scores))
+        n = int(ftr.view(np.uint16)[1])
+        return st, best.value, dis.value, scores, ftr.view(np.int16)[2:2 + n * 12].reshape(n, 12).copy(), n

@@ -1,0 +1,261 @@
+"""CPU tests that pin the oracle (no GPU).
+
+ * tier (ii) (own restatement) against the committed golden fixtures, which were produced by
+   tier (i) = the reference's own .C objects  -> runs anywhere, including the GPU box;
+ * tier (ii) against tier (i) live on fresh random inputs, and the regenerated constant tables
+   against the reference headers / assembly table -> only where /root/reference exists.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as ol
+from conftest import REFERENCE, needs_reference
+from stm32_speech_recognition_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return ol.Oracle(max_frames=119)
+
+
+def _ref_text(rel):
+    return open(os.path.join(REFERENCE, rel), "rb").read().decode("latin1")
+
+
+# ----------------------------------------------------------------------------- tables
+@needs_reference
+def test_tables_regenerate_reference_headers(oracle):
+    """MFCC_Arg.h:6-44 -- every constant table regenerates with 0 mismatches."""
+    src = _ref_text("Src/Speech_Recog/MFCC_Arg.h")
+    t = oracle.tables()
+    for name, key in (("hamm", "hamm"), ("tri_cen", "tri_cen"), ("tri_odd", "tri_odd"), ("tri_even", "tri_even"),
+                      ("dct_arg", "dct")):
+        m = re.search(name + r"\[\]\s*=\s*\{([^}]*)\}", src)
+        want = np.array([int(v) for v in re.findall(r"-?\d+", m.group(1))])
+        got = t[key].astype(np.int64)
+        assert len(want) == len(got), name
+        assert (want != got).sum() == 0, name
+
+
+@needs_reference
+def test_twiddles_regenerate_asm_table():
+    """cr4_fft_1024_stm32.s:285-629 -- all 1020 (Kr', Ki) entries regenerate exactly."""
+    import ctypes as C
+    s = _ref_text("Src/BSP/cr4_fft_1024_stm32.s")
+    tab = s[s.index("TableFFT_V7", s.index("passloop_v7")):]
+    tab = tab[tab.index("\n"):]
+    hw = [int(h, 16) for line in tab.splitlines() if "DCW" in line
+          for h in re.findall(r"0x([0-9a-fA-F]{4})", line.split(";")[0])]
+    hw = np.array(hw, dtype=np.uint16).view(np.int16)
+    assert len(hw) == 2040
+    L = ol.Oracle().L
+    kr = np.zeros(1020, dtype=np.int16)
+    ki = np.zeros(1020, dtype=np.int16)
+    L.sr_oracle_q15_twiddles(kr.ctypes.data_as(C.c_void_p), ki.ctypes.data_as(C.c_void_p))
+    assert (hw[0::2] != kr).sum() == 0 and (hw[1::2] != ki).sum() == 0
+
+
+# ----------------------------------------------------------------------------- golden (tier i outputs)
+def _pack(frame_real):
+    return frame_real.view(np.uint16).astype(np.uint32)
+
+
+def test_fft_mag_matches_golden(oracle, golden):
+    """rows 16.. of the FFT fixture are zero-padded real frames, the shape fft() (MFCC.C:27-62) feeds."""
+    fin, fout = golden["fft_in"], golden["fft_out"]
+    for i in range(16, fin.shape[0]):
+        frame = (fin[i, :160] & 0xFFFF).astype(np.uint16).view(np.int16)
+        re = (fout[i, :512] & 0xFFFF).astype(np.uint16).view(np.int16).astype(np.int32)
+        im = (fout[i, :512] >> 16).astype(np.uint16).view(np.int16).astype(np.int32)
+        want = (np.sqrt((re * re + im * im).astype(np.float32)) * np.float32(10)).astype(np.uint32)
+        assert np.array_equal(oracle.fft_mag(frame), want)
+
+
+def test_vad_mfcc_match_golden(oracle, golden):
+    pcm = golden["pcm"]
+    for b in range(pcm.shape[0]):
+        rc, a = oracle.noise_atap(pcm[b])
+        assert rc == 0 and a.astuple() == tuple(golden["atap"][b])
+        seg = oracle.vad(pcm[b], a)
+        assert np.array_equal(seg, golden["seg"][b])
+        n, m = oracle.mfcc(pcm[b], seg[0], seg[1], a)
+        assert n == golden["frm_num"][b]
+        assert np.array_equal(m, golden["mfcc"][b, :n])
+
+
+def test_direct_mfcc_edge_cases_match_golden(oracle, golden):
+    """all-zero frames (log(0)), s16 wrap after windowing, full-range u16 codes."""
+    dp, dmid, dm = golden["direct_pcm"], golden["direct_mid"], golden["direct_mfcc"]
+    nfd = dm.shape[1]
+    for d in range(dp.shape[0]):
+        a = ol.Atap(int(dmid[d]), 10, 2, 1000)
+        n, m = oracle.mfcc(dp[d], 1, 1 + 160 + 80 * (nfd - 1), a)
+        assert n == nfd and np.array_equal(m, dm[d])
+    assert not dm[0].any() and dm[1].any()
+
+
+def test_dtw_matches_golden(oracle, golden):
+    ln, da, db, dd = golden["dtw_len"], golden["dtw_a"], golden["dtw_b"], golden["dtw_dis"]
+    pad = np.zeros((1, 12), dtype=np.int16)
+    got = np.array([oracle.dtw(np.concatenate([da[p], pad]), ln[p, 0], np.concatenate([db[p], pad]), ln[p, 1])
+                    for p in range(len(dd))], dtype=np.uint32)
+    assert np.array_equal(got, dd)
+    assert (dd == ol.DIS_ERR).sum() > 20 and (dd != ol.DIS_ERR).sum() > 100
+
+
+def store_to_templates(store, stride=4096, tmax=120, nc=12):
+    """Firmware flash image (Flash.H:11-20, MFCC.H:18-25) -> dense batched layout."""
+    K = len(store) // stride
+    tm = np.zeros((K, tmax, nc), dtype=np.int16)
+    tf = np.zeros(K, dtype=np.uint32)
+    tv = np.zeros(K, dtype=np.uint8)
+    for k in range(K):
+        slot = store[k * stride:(k + 1) * stride]
+        tv[k] = slot[:2].view(np.uint16)[0] == 12345
+        tf[k] = slot[2:4].view(np.uint16)[0]
+        body = slot[4:4 + 119 * nc * 2].view(np.int16)
+        tm[k, :119] = body.reshape(119, nc)
+    return tm, tf, tv
+
+
+def test_recognize_matches_golden(oracle, golden):
+    tm, tf, tv = store_to_templates(golden["store"])
+    tpl = oracle.make_templates(tm, tf, tv)
+    res, mf, sc = oracle.recognize_batch(golden["pcm"], tpl, n_threads=2)
+    assert np.array_equal(res["status"], golden["recg_status"])
+    assert np.array_equal(res["best_tpl"], golden["recg_best"])
+    assert np.array_equal(res["min_dis"], golden["recg_dis"])
+    assert np.array_equal(sc, golden["recg_scores"])
+    assert (sc[:, 7] == ol.DIS_ERR).all()  # the erased slot
+
+
+# ----------------------------------------------------------------------------- edge behaviour of the restatement
+def test_noise_atap_bad_length_is_silent_noop(oracle):
+    x = np.full(2400, 2048, dtype=np.uint16)
+    rc, a = oracle.noise_atap(x, n_len=2399)  # VAD.C:33-36
+    assert rc == 1 and a.astuple() == (0, 0, 0, 0)
+
+
+def test_vad_failure_and_status(oracle):
+    x = np.full(16000, 2048, dtype=np.uint16)  # silence: no segment
+    tpl = oracle.make_templates(np.zeros((2, 120, 12), np.int16), np.array([10, 10], np.uint32))
+    res, _, sc = oracle.recognize_batch(x[None], tpl)
+    assert res["status"][0] == ol.ST_VAD_FAIL and res["min_dis"][0] == ol.DIS_ERR and res["best_tpl"][0] == 0
+    assert (sc == ol.DIS_ERR).all()
+
+
+def test_mfcc_too_long_returns_zero_frames(oracle):
+    x = np.full(16000, 2048, dtype=np.uint16)
+    a = ol.Atap(2048, 10, 2, 1000)
+    n, _ = oracle.mfcc(x, 1, 1 + 160 + 80 * 119, a)  # 120 frames > vv_frm_max (MFCC.C:103-107)
+    assert n == 0
+    n, _ = oracle.mfcc(x, 1, 1 + 160 + 80 * 118, a)
+    assert n == 119
+
+
+def test_dtw_gates_and_identity(oracle):
+    rng = np.random.default_rng(5)
+    a = rng.integers(-500, 500, (121, 12)).astype(np.int16)
+    assert oracle.dtw(a, 50, a, 50) == 0
+    assert oracle.dtw(a, 101, a, 50) == ol.DIS_ERR  # in > 2*mdl (DTW.C:133)
+    assert oracle.dtw(a, 24, a, 50) == ol.DIS_ERR   # 2*in < mdl
+    assert oracle.dtw(a, 100, a, 50) != ol.DIS_ERR
+    assert oracle.dtw(a, 25, a, 50) != ol.DIS_ERR
+
+
+def test_synth_yields_exact_frame_count():
+    """The benchmark generator must give exactly T frames through the oracle's VAD (T = 256 shape)."""
+    o = ol.Oracle(max_frames=256)
+    bank = synth.word_bank(10)
+    T = 256
+    x = synth.as_u16_numpy(synth.make_utterances(np.arange(6) % 10, [T] * 6, seed=3, bank=bank))
+    assert x.shape[1] == 25360
+    for b in range(6):
+        rc, a = o.noise_atap(x[b])
+        seg = o.vad(x[b], a)
+        assert tuple(seg[:2]) == (3200, 3200 + 80 * (T - 1) + 160)
+        n, _ = o.mfcc(x[b], seg[0], seg[1], a)
+        assert n == T
+
+
+# ----------------------------------------------------------------------------- tier (ii) == tier (i), live
+@needs_reference
+def test_tier2_equals_tier1_on_fresh_inputs(oracle):
+    r = ol.RefLib()
+    rng = np.random.default_rng(77)
+    bank = synth.word_bank(7, seed=9)
+    B = 24
+    frames = rng.integers(20, 120, B)
+    pcm = np.zeros((B, 16000), dtype=np.uint16)
+    for b in range(B):
+        pcm[b] = synth.as_u16_numpy(synth.make_utterances([b % 7], [frames[b]], seed=1000 + b, bank=bank, S=16000,
+                                                          gain=float(rng.choice([0.3, 1.0, 1.0, 4.0])),
+                                                          quiet_sigma=float(rng.choice([4.0, 8.0]))))[0]
+    feats = []
+    for b in range(B):
+        a1, s1 = r.vad(pcm[b])
+        rc, a2 = oracle.noise_atap(pcm[b])
+        s2 = oracle.vad(pcm[b], a2)
+        assert a1.astuple() == a2.astuple() and np.array_equal(s1, s2)
+        if s1[1] < 0 or s1[0] < 1:
+            continue
+        n1, m1, f1 = r.mfcc(pcm[b], s1[0], s1[1], a1)
+        n2, m2 = oracle.mfcc(pcm[b], s2[0], s2[1], a2)
+        assert n1 == n2 and np.array_equal(m1, m2)
+        if n1:
+            feats.append((n1, m1, f1))
+    assert len(feats) >= 16
+    pad = np.zeros((2, 12), dtype=np.int16)
+    for i in range(len(feats)):
+        for j in range(len(feats)):
+            d1 = r.dtw(feats[i][2], feats[j][2])
+            d2 = oracle.dtw(np.concatenate([feats[i][1], pad]), feats[i][0], np.concatenate([feats[j][1], pad]),
+                            feats[j][0])
+            assert d1 == d2
+
+
+@needs_reference
+def test_tier2_dtw_equals_tier1_random_features(oracle):
+    r = ol.RefLib()
+    rng = np.random.default_rng(123)
+    for p in range(1500):
+        na, nb = (int(v) for v in rng.integers(1, 120, 2))
+        amp = int(rng.choice([100, 1500, 32767]))
+        a = rng.integers(-amp, amp + 1, (119, 12)).astype(np.int16)
+        b = rng.integers(-amp, amp + 1, (119, 12)).astype(np.int16)
+        d1 = r.dtw(ol.RefLib.make_ftr(a, na), ol.RefLib.make_ftr(b, nb))
+        d2 = oracle.dtw(np.concatenate([a, np.zeros((1, 12), np.int16)]), na,
+                        np.concatenate([b, np.zeros((1, 12), np.int16)]), nb)
+        assert d1 == d2, (p, na, nb)
+
+
+@needs_reference
+def test_reference_adc_dump_probe_values(oracle):
+    """SURVEY.md section 8c probe: the reference's own 12-bit capture 'STM32 123.txt' (read in place)."""
+    txt = _ref_text("Matlab/语音样本/STM32 123.txt".encode("utf-8").decode("utf-8"))
+    vals = np.array([int(x) for x in re.findall(r"\d+", txt)], dtype=np.uint16)
+    assert len(vals) == 16000
+    rc, a = oracle.noise_atap(vals)
+    assert a.astuple() == (2213, 172, 2, 9524)
+    seg = oracle.vad(vals, a)
+    assert list(seg) == [3920, 6880, 8640, 11440, 13360, -1]
+    n0, m0 = oracle.mfcc(vals, seg[0], seg[1], a)
+    n1, m1 = oracle.mfcc(vals, seg[2], seg[3], a)
+    assert (n0, n1) == (36, 34)
+    assert list(m0[0]) == [353, 719, 516, 439, -174, -29, -18, -48, 29, -113, -23, -5]
+    pad = np.zeros((1, 12), np.int16)
+    assert oracle.dtw(np.concatenate([m0, pad]), n0, np.concatenate([m1, pad]), n1) == 3874
+    r = ol.RefLib()
+    a1, s1 = r.vad(vals)
+    assert a1.astuple() == a.astuple() and np.array_equal(s1, seg)
