@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- utterances/s of the isolated-word recognition hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = one pass of the whole hot path (noise_atap -> VAD -> MFCC -> greedy DTW x K templates ->
+argmin) over one batch of synthetic capture buffers that is already resident in HBM.
+Workload at every N (weak scaling): BASELINE.json configs[2] per GPU -- 65 536 utterances of 256 frames
+(25 360-sample 8 kHz capture buffers) x 100 templates, 12 MFCC coefficients; utterances are sharded
+over ranks, templates replicated, and each step ends with one RCCL all-gather of the per-template score
+matrix (N > 1 only).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from stm32_speech_recognition_amd import Engine, synth  # noqa: E402
+from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch  # noqa: E402
+
+T = 256            # frames per utterance (metric: "256-frame, 100 templates")
+K = 100            # templates
+N_WORDS = 20       # vocabulary the templates are spoken from (comm_num, Flash.H:17)
+MAX_FRAMES = 320   # frame cap: templates run 192..320 frames
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes_per_utt(S, T, C, K):
+    """compulsory HBM traffic of the whole path per utterance (templates amortised to 0)."""
+    return 2 * S + 2 * (2 * T * C) + 4 * K + 16
+
+
+def mfcc_kernel_bytes_per_utt(T, C):
+    """k_mfcc alone: speech span read once (+1 pre-emphasis halo sample), MFCC rows written once, 48 B record."""
+    return 2 * (80 * (T - 1) + 160 + 1) + 2 * T * C + 48
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="utterances timed on the host cores")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B = args.batch
+    S = synth.buf_len_for(T)
+
+    eng = Engine(max_frames=MAX_FRAMES, device=local_rank)
+
+    # ---- templates: K synthetic words through the SAME front end (main.c:121-138 save_mdl) ----------
+    bank = synth.word_bank(N_WORDS)
+    rng = np.random.default_rng(2026)
+    tfr = rng.integers(192, 321, K)
+    tpcm = synth.make_utterances(np.arange(K) % N_WORDS, tfr, seed=77, bank=bank, S=synth.buf_len_for(320), device=dev)
+    tvad, tmf = eng.features_dev(tpcm)
+    torch.cuda.synchronize()
+    tv = vad_from_torch(tvad)
+    assert (tv["status"] == 0).all() and np.array_equal(tv["frm_num"], tfr), "template front end did not yield the planned frame counts"
+    tm = np.concatenate([tmf.cpu().numpy(), np.zeros((K, 1, 12), np.int16)], 1)
+    eng.set_templates_dense(tm, tfr.astype(np.uint32))
+    del tpcm, tvad, tmf
+
+    # ---- this rank's shard of utterances, generated straight into HBM -------------------------------
+    words = torch.from_numpy(rng.integers(0, N_WORDS, (world, B)))[rank]
+    pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev)
+    out = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
+    gathered = torch.empty(world * B, K, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        eng.recognize_dev(pcm, out)
+        if world > 1:  # the path's one exchange step: all-gather of per-template scores over xGMI
+            dist.all_gather_into_tensor(gathered, out["scores"])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # sanity on real outputs (outside the timed region): every utterance must have exactly T frames
+    res = results_from_torch(out["results"])
+    assert (res["status"] == 0).all() and (res["frm_num"] == T).all(), "workload is not 256-frame utterances"
+    acc = float((res["best_tpl"] % N_WORDS == words.numpy()).mean())
+
+    eng.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    stage = eng.stage_ms()  # hipEvent timings of the timed steps, on the launch stream
+    eng.set_profiling(False)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        C = 12
+        by_path = algorithmic_bytes_per_utt(S, T, C, K)
+        by_mfcc = mfcc_kernel_bytes_per_utt(T, C)
+        ach = by_mfcc * B / (stage["mfcc"] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_mfcc_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "utterances/sec (256-frame, 100 templates)",
+            "value": value,
+            "unit": "utterances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "s16/s32 fixed point (+ f32 sqrt)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: batch=65536 utterances x 100 templates per GPU, 256 frames, "
+                                   "12-coef MFCC, 8 kHz 25360-sample capture buffers",
+                       "batch_per_gpu": B, "templates": K, "frames": T, "buf_len": S,
+                       "parallelism": f"utterance-sharded x{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "k_mfcc", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": by_mfcc * B, "kernel_ms": stage["mfcc"],
+                         "note": "path is integer-VALU-bound, not HBM-bound (DESIGN.md); fraction reported as mandated"},
+            "roofline_path": {"bytes_per_utt": by_path, "achieved": by_path * B / (stage["total"] * 1e-3) / 1e9,
+                              "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms": stage,
+            "top1_word_accuracy": acc,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pcm, eng, out, tm, tfr, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pcm, eng, out, tm, tfr, n):
+    """The CPU restatement of the reference C path (oracle tier ii, validated against the reference's own
+    objects) timed on this box's host cores over the first n utterances of the same batch; also used to
+    cross-check the GPU results of those utterances."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    cores = os.cpu_count() or 1
+    orc = ol.Oracle(max_frames=MAX_FRAMES)
+    tpl = orc.make_templates(tm, tfr.astype(np.uint32))
+    host = synth.as_u16_numpy(pcm[:n])
+    orc.recognize_batch(host[:cores * 2], tpl, n_threads=cores, want_mfcc=False, want_scores=False)  # warm-up
+    t0 = time.perf_counter()
+    ores, _, osc = orc.recognize_batch(host, tpl, n_threads=cores, want_mfcc=False, want_scores=True)
+    dt = time.perf_counter() - t0
+    gsc = out["scores"][:n].cpu().numpy().view(np.uint32)
+    gres = results_from_torch(out["results"][:n])
+    match = bool(np.array_equal(gsc, osc) and np.array_equal(gres["best_tpl"], ores["best_tpl"]))
+    return {"value": n / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} utterances of the timed batch, {cores} host threads, gcc -O2 oracle (tier ii)",
+            "seconds": dt, "gpu_results_identical_on_sample": match}
+
+
+if __name__ == "__main__":
+    main()

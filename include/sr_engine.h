@@ -1,0 +1,197 @@
+/*
+ * sr_engine.h -- C ABI of the MI355X-native isolated-word recognition engine.
+ *
+ * Drop-in boundary for the hot path of gk969/stm32-speech-recognition
+ * (noise_atap -> VAD -> get_mfcc/fft/cr4_fft_1024_stm32 -> dtw -> spch_recg).
+ * The reference has no plugin API; its boundary is the set of C functions that
+ * Src/APP/main.c calls (main.c:121-138, 249-296).  This header declares
+ *
+ *   1. the batched engine API the benchmark drives (no reference counterpart:
+ *      the firmware recognises one utterance at a time), and
+ *   2. the reference's own scalar entry points, same names / argument meaning /
+ *      sentinel error behaviour, each executed as a 1-item dispatch of the same
+ *      HIP kernels (there is NO CPU fallback anywhere in this library: every
+ *      entry point fails with SR_ERR_NO_DEVICE if no gfx950 device is usable).
+ *
+ * Plain C types only; every pointer is caller-owned.  Thread-safety: distinct
+ * sr_engine handles are independent; one handle must not be used concurrently.
+ * The scalar reference-compatible symbols share one implicit handle and are,
+ * like the reference (file-scope statics in MFCC.C:14-15, DTW.C:65-68,
+ * main.c:22-25), not re-entrant.
+ */
+#ifndef SR_ENGINE_H
+#define SR_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status / errors */
+#define SR_OK 0
+#define SR_ERR_NO_DEVICE 1   /* no HIP device / not gfx950 / HIP runtime error */
+#define SR_ERR_BAD_CONFIG 2  /* configuration not supported by the kernels */
+#define SR_ERR_BAD_ARG 3     /* null pointer, bad alignment, size out of range */
+#define SR_ERR_NO_TEMPLATES 4
+#define SR_ERR_HIP 5
+
+/* per-utterance status in sr_result.status (the reference's sentinel returns) */
+#define SR_ST_OK 0
+#define SR_ST_VAD_FAIL 1  /* valid_voice[0].end == NULL            main.c:261-266 */
+#define SR_ST_MFCC_FAIL 2 /* frm_num == 0 (segment > max_frames)   main.c:269-274, MFCC.C:103-107 */
+#define SR_ST_SEG_OOB 3   /* segment starts at sample < 1: the reference would read before VcBuf (MFCC.C:119) */
+
+#define SR_DIS_ERR 0xFFFFFFFFu /* dis_err / dis_max, DTW.H:4-5 */
+#define SR_SAVE_MASK 12345u    /* save_mask, Flash.H:11 */
+
+/* ------------------------------------------------------------------ configuration */
+typedef struct sr_config {
+    uint32_t fs;            /* ADC.H:7       8000 */
+    uint32_t frame_time_ms; /* VAD.H:5       20  -> frame_len 160 */
+    uint32_t frame_mov_ms;  /* VAD.H:6       10  -> hop 80 */
+    uint32_t nfft;          /* MFCC.H:8      1024 */
+    uint32_t n_mel;         /* MFCC.H:12     24 */
+    uint32_t n_coef;        /* MFCC.H:13     12 */
+    uint32_t max_frames;    /* MFCC.H:15-16  119 in the firmware; runtime cap here (<= 16383) */
+    uint32_t noise_len_ms;  /* ADC.H:10      300 -> atap_len 2400 */
+    uint32_t max_seg;       /* VAD.H:4       3 */
+    int32_t device;         /* HIP device ordinal; -1 = current device */
+} sr_config;
+
+/* adaptive thresholds, VAD.H:10-16 (same field order and widths) */
+typedef struct sr_atap {
+    uint32_t mid_val;
+    uint16_t n_thl;
+    uint16_t z_thl;
+    uint32_t s_thl;
+} sr_atap;
+
+#define SR_MAX_SEG 3
+/* what the VAD stage leaves per utterance (device- or host-resident), 48 bytes */
+typedef struct sr_vad_rec {
+    sr_atap atap;                /* noise_atap output */
+    int32_t seg[2 * SR_MAX_SEG]; /* start/end sample offsets of up to 3 segments, -1 = NULL (VAD.H:18-22) */
+    uint32_t frm_num;            /* frames of segment 0 per MFCC.C:102-107 (0 on any failure) */
+    uint32_t status;             /* SR_ST_* */
+    uint32_t _pad;
+} sr_vad_rec;
+
+/* recognition record, 16 bytes: the argmin of main.c:276-295 */
+typedef struct sr_result {
+    uint32_t best_tpl; /* template slot of the first minimum (strict <, main.c:285) */
+    uint32_t min_dis;  /* *mtch_dis; SR_DIS_ERR if nothing matched */
+    uint32_t frm_num;  /* frames of segment 0 */
+    uint32_t status;   /* SR_ST_* */
+} sr_result;
+
+typedef struct sr_engine sr_engine;
+
+/* ------------------------------------------------------------------ lifecycle */
+void sr_default_config(sr_config *cfg); /* the reference's compile-time constants */
+int sr_create(const sr_config *cfg, sr_engine **out);
+void sr_destroy(sr_engine *h);
+const char *sr_last_error(void); /* thread-local text of the last failure */
+
+/* ------------------------------------------------------------------ template store
+ * The firmware keeps templates as v_ftr_tag images in MCU flash at a 4 KiB stride
+ * (Flash.H:11-20, MFCC.H:18-25: u16 save_sign | u16 frm_num | s16 mfcc[]), and
+ * spch_recg scans every slot in address order (main.c:279-291). */
+int sr_set_templates(sr_engine *h, const void *store, uint32_t n_slots, uint32_t stride_bytes);
+/* dense batched layout: mfcc[k*tpl_stride + frame*n_coef + c]; valid[k]!=0 <=> save_sign==12345 */
+int sr_set_templates_dense(sr_engine *h, const int16_t *mfcc, const uint32_t *frames, const uint8_t *valid,
+                           uint32_t n_templates, uint32_t tpl_stride);
+uint32_t sr_num_templates(const sr_engine *h);
+
+/* ------------------------------------------------------------------ batched recognition
+ * B capture buffers of buf_len samples, buffer b at pcm + b*pcm_stride (in samples).
+ * Outputs (each may be NULL except results):
+ *   results[B], scores[B*K] (cur_dis of every slot, main.c:283), mfcc[B*max_frames*n_coef]
+ *   (frame-major, rows >= frm_num zeroed), vad[B].
+ *
+ * sr_recognize_batch:      HOST buffers; stages them through HBM (PCIe-inclusive).
+ * sr_recognize_batch_dev:  DEVICE buffers already resident in HBM, enqueued on `stream`
+ *                          (a hipStream_t; NULL = default stream), asynchronous.
+ *                          pcm must be 16-byte aligned and pcm_stride a multiple of 8.
+ */
+int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                       sr_result *results, uint32_t *scores, int16_t *mfcc, sr_vad_rec *vad);
+int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                           sr_result *d_results, uint32_t *d_scores, int16_t *d_mfcc, sr_vad_rec *d_vad,
+                           void *stream);
+
+/* stage-level entry points on DEVICE buffers (same kernels the full path launches) */
+int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                     sr_vad_rec *d_vad, void *stream);
+int sr_mfcc_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t B, const sr_vad_rec *d_vad,
+                      int16_t *d_mfcc, void *stream);
+int sr_dtw_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_vad, uint32_t B, uint32_t *d_scores,
+                     sr_result *d_results, void *stream);
+
+/* stage-level entry points on HOST buffers (copy in, launch, copy out) */
+int sr_vad_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                 sr_vad_rec *vad);
+/* MFCC of segment [start[b], end[b]) of buffer b with mid value mid[b]; frm_num[b] receives the frame count */
+int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                  const int32_t *start, const int32_t *end, const uint32_t *mid, int16_t *mfcc, uint32_t *frm_num);
+/* all-pairs greedy DTW of B feature sequences (in_mfcc[b*max_frames*n_coef], in_frames[b]) against the store */
+int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores,
+                 sr_result *results);
+/* generic 1024-point Q15 FFT of n independent packed-complex arrays (re = low half, im = high half) */
+int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
+
+/* ------------------------------------------------------------------ measurement hooks (bench.py)
+ * With profiling on, sr_recognize_batch_dev brackets each kernel with hipEvents on the launch stream;
+ * sr_get_stage_ms synchronises and returns per-kernel milliseconds averaged over every call made
+ * since sr_set_profiling(h, 1):  ms[0] VAD, ms[1] MFCC (frame kernel), ms[2] DTW, ms[3] argmin,
+ * ms[4] whole call (first launch -> last kernel done). */
+int sr_set_profiling(sr_engine *h, int on);
+int sr_get_stage_ms(sr_engine *h, float ms[5]);
+
+/* ------------------------------------------------------------------ reference-compatible scalar symbols
+ * Exact reference signatures (u8/u16/u32/s16 = stdint fixed widths, stm32f10x.h:421-439).
+ * Each one replaces the reference function cited; all run on the GPU through an implicit
+ * default engine (reference constants, max_frames 119). */
+typedef struct {
+    uint32_t mid_val;
+    uint16_t n_thl;
+    uint16_t z_thl;
+    uint32_t s_thl;
+} atap_tag; /* VAD.H:10-16 */
+typedef struct {
+    uint16_t *start;
+    uint16_t *end;
+} valid_tag; /* VAD.H:18-22 */
+#define SR_VV_FRM_MAX 119 /* MFCC.H:15-16 */
+#pragma pack(push, 1)
+typedef struct {
+    uint16_t save_sign;
+    uint16_t frm_num;
+    int16_t mfcc_dat[SR_VV_FRM_MAX * 12];
+} v_ftr_tag; /* MFCC.H:18-25, 2860 bytes */
+#pragma pack(pop)
+
+void noise_atap(const uint16_t *noise, uint16_t n_len, atap_tag *atap);                          /* VAD.H:24, VAD.C:22 */
+void VAD(const uint16_t *vc, uint16_t buf_len, valid_tag *valid_voice, atap_tag *atap_arg);      /* VAD.H:25, VAD.C:97 */
+void get_mfcc(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg);                           /* MFCC.H:27, MFCC.C:86 */
+uint32_t *fft(int16_t *dat_buf, uint16_t buf_len);                                               /* MFCC.C:27 */
+void cr4_fft_1024_stm32(void *pssOUT, void *pssIN, uint16_t Nbin);                               /* MFCC.C:12, .s:219 */
+uint32_t get_dis(int16_t *frm_ftr1, int16_t *frm_ftr2);                                          /* DTW.C:45 */
+uint8_t dtw_limit(uint16_t x, uint16_t y);                                                       /* DTW.C:76 */
+uint32_t dtw(v_ftr_tag *ftr_in, v_ftr_tag *frt_mdl);                                             /* DTW.H:7, DTW.C:120 */
+uint8_t *spch_recg(uint16_t *v_dat, uint32_t *mtch_dis);                                         /* main.c:249 */
+/* BASELINE.json's north-star spellings; they do not exist in the reference -> aliases of get_mfcc */
+void GetMfcc(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg);
+void MFCC_Comp(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg);
+
+/* The firmware reads its template store at a fixed flash address (Flash.H:19-20) and returns a
+ * pointer into commstr[] (main.c:31,295).  The scalar spch_recg needs both handed over: */
+int sr_compat_set_templates(const void *store, uint32_t n_slots, uint32_t stride_bytes);
+int sr_compat_set_labels(const uint8_t *labels, uint32_t n_labels, uint32_t label_stride, uint32_t ftr_per_comm);
+sr_engine *sr_compat_engine(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_ENGINE_H */

@@ -1,0 +1,211 @@
+// The reference's own scalar entry points (exact names and signatures), each a 1-item dispatch of
+// the HIP kernels through an implicit default engine built with the firmware's constants
+// (ADC.H:7-11, VAD.H:4-8, MFCC.H:7-16, Flash.H:11-20).  Like the firmware they are not re-entrant.
+// There is no error channel in these signatures: if no gfx950 device can be used the process is
+// stopped with a message rather than silently computing on the CPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sr_device.h"
+#include "sr_tables.h"
+
+struct sr_engine;
+namespace sr {
+int engine_fft_mag(sr_engine *h, const int16_t *frame, uint32_t len, uint32_t *mag, uint32_t *raw_hi);
+int engine_get_dis(sr_engine *h, const int16_t *a, const int16_t *b, uint32_t *out);
+int engine_dtw_limit(sr_engine *h, uint16_t x, uint16_t y, int X1, int X2, int in_n, int mdl_n, uint8_t *out);
+int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, const sr_atap *atap, sr_vad_rec *rec);
+int engine_noise_atap(sr_engine *h, const uint16_t *noise, uint32_t n_len, sr_atap *out);
+}  // namespace sr
+
+namespace {
+
+constexpr uint32_t kVcBufLen = 16000;  // ADC.H:9
+constexpr uint32_t kAtapFrm = 240;     // VAD.C:13-14
+
+sr_engine *g_engine = nullptr;  // recognition engine (holds the compat template store)
+sr_engine *g_pair = nullptr;    // engine whose store is the single model of a dtw() call
+
+[[noreturn]] void die(const char *what)
+{
+    std::fprintf(stderr, "sr_engine (reference-compatible symbol %s): %s\n", what, sr_last_error());
+    std::abort();
+}
+
+sr_engine *engine(const char *who)
+{
+    if (!g_engine) {
+        sr_config c;
+        sr_default_config(&c);
+        if (sr_create(&c, &g_engine) != SR_OK) die(who);
+    }
+    return g_engine;
+}
+sr_engine *pair_engine(const char *who)
+{
+    if (!g_pair) {
+        sr_config c;
+        sr_default_config(&c);
+        if (sr_create(&c, &g_pair) != SR_OK) die(who);
+    }
+    return g_pair;
+}
+
+// DTW.C:65-68 file statics, observable through dtw_limit()
+uint16_t g_X1 = 0, g_X2 = 0, g_in_frm = 0, g_mdl_frm = 0;
+
+uint32_t g_fft_out[1024];  // MFCC.C:14, fft() returns a pointer to it
+
+// commstr[] of main.c:31 -- 3-byte labels, GB2312 for the eight direction/size words
+const uint8_t kDefaultLabels[18][3] = {
+    {'0', ' ', 0}, {'1', ' ', 0}, {'2', ' ', 0}, {'3', ' ', 0}, {'4', ' ', 0}, {'5', ' ', 0},
+    {'6', ' ', 0}, {'7', ' ', 0}, {'8', ' ', 0}, {'9', ' ', 0}, {0xC9, 0xCF, 0}, {0xCF, 0xC2, 0},
+    {0xC7, 0xB0, 0}, {0xBA, 0xF3, 0}, {0xD7, 0xF3, 0}, {0xD3, 0xD2, 0}, {0xB4, 0xF3, 0}, {0xD0, 0xA1, 0}};
+std::vector<uint8_t> g_labels(&kDefaultLabels[0][0], &kDefaultLabels[0][0] + sizeof kDefaultLabels);
+uint32_t g_n_labels = 18, g_label_stride = 3, g_ftr_per_comm = 4;  // Flash.H:15
+uint8_t g_empty_label[1] = {0};
+
+}  // namespace
+
+extern "C" {
+
+sr_engine *sr_compat_engine(void) { return engine("sr_compat_engine"); }
+
+int sr_compat_set_templates(const void *store, uint32_t n_slots, uint32_t stride_bytes)
+{
+    return sr_set_templates(engine("sr_compat_set_templates"), store, n_slots, stride_bytes);
+}
+
+int sr_compat_set_labels(const uint8_t *labels, uint32_t n_labels, uint32_t label_stride, uint32_t ftr_per_comm)
+{
+    if (!labels || !n_labels || !label_stride || !ftr_per_comm) return SR_ERR_BAD_ARG;
+    g_labels.assign(labels, labels + (size_t)n_labels * label_stride);
+    g_n_labels = n_labels;
+    g_label_stride = label_stride;
+    g_ftr_per_comm = ftr_per_comm;
+    return SR_OK;
+}
+
+// VAD.C:22-71
+void noise_atap(const uint16_t *noise, uint16_t n_len, atap_tag *atap)
+{
+    if (n_len == 0 || (n_len % kAtapFrm) != 0) return;  // VAD.C:33-36: silent return
+    sr_atap a;
+    if (sr::engine_noise_atap(engine("noise_atap"), noise, n_len, &a) != SR_OK) die("noise_atap");
+    atap->mid_val = a.mid_val;
+    atap->n_thl = a.n_thl;
+    atap->z_thl = a.z_thl;
+    atap->s_thl = a.s_thl;
+}
+
+// VAD.C:97-218
+void VAD(const uint16_t *vc, uint16_t buf_len, valid_tag *valid_voice, atap_tag *atap_arg)
+{
+    for (int i = 0; i < SR_MAX_SEG; i++) valid_voice[i].start = valid_voice[i].end = nullptr;  // VAD.C:115-119
+    if (buf_len <= sr::kFrameLen) return;                                                      // loop of VAD.C:121 is empty
+    sr_atap a{atap_arg->mid_val, atap_arg->n_thl, atap_arg->z_thl, atap_arg->s_thl};
+    sr_vad_rec rec;
+    if (sr::engine_vad_with_atap(engine("VAD"), vc, buf_len, &a, &rec) != SR_OK) die("VAD");
+    for (int i = 0; i < SR_MAX_SEG; i++) {
+        if (rec.seg[2 * i] != -1) valid_voice[i].start = (uint16_t *)vc + rec.seg[2 * i];
+        if (rec.seg[2 * i + 1] != -1) valid_voice[i].end = (uint16_t *)vc + rec.seg[2 * i + 1];
+    }
+}
+
+// MFCC.C:86-191
+void get_mfcc(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg)
+{
+    const ptrdiff_t len = valid->end - valid->start;
+    if (len < (ptrdiff_t)sr::kFrameLen) {  // MFCC.C:102-113: either the cap trips or the loop body never runs
+        v_ftr->frm_num = 0;
+        return;
+    }
+    sr_engine *h = engine("get_mfcc");
+    const int32_t start = 1, end = (int32_t)len + 1;  // buffer handed over begins at start[-1] (MFCC.C:119)
+    const uint32_t mid = atap_arg->mid_val;
+    std::vector<int16_t> out((size_t)SR_VV_FRM_MAX * 12);
+    uint32_t n = 0;
+    if (sr_mfcc_batch(h, valid->start - 1, (uint64_t)len + 1, (uint32_t)len + 1, 1, &start, &end, &mid, out.data(), &n) !=
+        SR_OK)
+        die("get_mfcc");
+    v_ftr->frm_num = (uint16_t)n;  // 0 when the segment exceeds vv_frm_max (MFCC.C:103-107)
+    if (n) std::memcpy(v_ftr->mfcc_dat, out.data(), (size_t)n * 12 * sizeof(int16_t));
+}
+void GetMfcc(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg) { get_mfcc(valid, v_ftr, atap_arg); }
+void MFCC_Comp(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg) { get_mfcc(valid, v_ftr, atap_arg); }
+
+// MFCC.C:27-62
+uint32_t *fft(int16_t *dat_buf, uint16_t buf_len)
+{
+    if (buf_len > sr::kNfft) return nullptr;  // MFCC.C:32-35
+    if (sr::engine_fft_mag(engine("fft"), dat_buf, buf_len, g_fft_out, g_fft_out + sr::kBins) != SR_OK) die("fft");
+    return g_fft_out;
+}
+
+// cr4_fft_1024_stm32.s:219-281
+void cr4_fft_1024_stm32(void *pssOUT, void *pssIN, uint16_t Nbin)
+{
+    (void)Nbin;  // "this optimized FFT function can only convert 1024 points" (.s:214-215)
+    if (sr_fft_q15_batch(engine("cr4_fft_1024_stm32"), (const uint32_t *)pssIN, (uint32_t *)pssOUT, 1) != SR_OK)
+        die("cr4_fft_1024_stm32");
+}
+
+// DTW.C:45-62
+uint32_t get_dis(int16_t *frm_ftr1, int16_t *frm_ftr2)
+{
+    uint32_t d = 0;
+    if (sr::engine_get_dis(engine("get_dis"), frm_ftr1, frm_ftr2, &d) != SR_OK) die("get_dis");
+    return d;
+}
+
+// DTW.C:76-109 (uses the statics left by the last dtw() call)
+uint8_t dtw_limit(uint16_t x, uint16_t y)
+{
+    uint8_t o = 0;
+    if (sr::engine_dtw_limit(engine("dtw_limit"), x, y, g_X1, g_X2, g_in_frm, g_mdl_frm, &o) != SR_OK) die("dtw_limit");
+    return o;
+}
+
+// DTW.C:120-192
+uint32_t dtw(v_ftr_tag *ftr_in, v_ftr_tag *frt_mdl)
+{
+    g_in_frm = ftr_in->frm_num;
+    g_mdl_frm = frt_mdl->frm_num;
+    if (g_in_frm > g_mdl_frm * 2 || 2 * g_in_frm < g_mdl_frm) return SR_DIS_ERR;  // DTW.C:133-137
+    g_X1 = (uint16_t)((2 * g_mdl_frm - g_in_frm) / 3);
+    g_X2 = (uint16_t)((4 * g_in_frm - 2 * g_mdl_frm) / 3);
+    sr_engine *h = pair_engine("dtw");
+    const uint32_t mf = frt_mdl->frm_num, inf = ftr_in->frm_num;
+    if (mf > SR_VV_FRM_MAX || inf > SR_VV_FRM_MAX || inf == 0) {
+        std::fprintf(stderr, "dtw: frm_num outside the v_ftr_tag capacity\n");
+        std::abort();
+    }
+    // model -> 1-slot dense store (all 119 rows, so rows past frm_num read the caller's data as in DTW.C:152-154)
+    if (sr_set_templates_dense(h, frt_mdl->mfcc_dat, &mf, nullptr, 1, SR_VV_FRM_MAX * 12) != SR_OK) die("dtw");
+    uint32_t score = 0;
+    if (sr_dtw_batch(h, ftr_in->mfcc_dat, &inf, 1, &score, nullptr) != SR_OK) die("dtw");
+    return score;
+}
+
+// main.c:249-296
+uint8_t *spch_recg(uint16_t *v_dat, uint32_t *mtch_dis)
+{
+    sr_engine *h = engine("spch_recg");
+    if (sr_num_templates(h) == 0) {
+        std::fprintf(stderr, "spch_recg: no template store (call sr_compat_set_templates first)\n");
+        std::abort();
+    }
+    sr_result r;
+    if (sr_recognize_batch(h, v_dat, kVcBufLen, kVcBufLen, 1, &r, nullptr, nullptr, nullptr) != SR_OK) die("spch_recg");
+    *mtch_dis = r.min_dis;
+    if (r.status != SR_ST_OK) return nullptr;  // main.c:261-274 (VAD fail / MFCC fail)
+    const uint32_t comm = r.best_tpl / g_ftr_per_comm;  // main.c:292
+    if (comm >= g_n_labels) return g_empty_label;       // the firmware would index past commstr[]
+    return g_labels.data() + (size_t)comm * g_label_stride;
+}
+
+}  // extern "C"

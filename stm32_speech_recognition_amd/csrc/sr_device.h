@@ -1,0 +1,80 @@
+// Kernel argument blocks and launch entry points shared by the host engine and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/sr_engine.h"
+
+namespace sr {
+
+// device-resident constant tables (see sr_tables.h)
+struct DevTables {
+    const uint16_t *hamm;      // [160]
+    const uint16_t *tri_even;  // [512]
+    const uint16_t *tri_odd;   // [512]
+    const uint16_t *tri_cen;   // [24]
+    const int8_t *dct;         // [288]
+    const uint32_t *tw_a;      // [1020]
+    const uint32_t *tw_b;      // [1020]
+    const uint32_t *log_thr;   // [2220]
+};
+
+struct VadArgs {
+    const uint16_t *pcm;  // [B][pcm_stride], 16-byte aligned rows
+    uint64_t pcm_stride;  // samples
+    uint32_t buf_len;     // samples scanned by VAD (VcBuf_Len)
+    uint32_t noise_len;   // atap_len
+    uint32_t atap_frm;    // atap_frm_len (240)
+    uint32_t max_frames;  // vv_frm_max
+    uint32_t max_seg;     // max_vc_con
+    uint32_t B;
+    sr_vad_rec *vad;      // [B]
+    const sr_atap *atap_in;  // optional [B]: use these thresholds instead of running noise_atap
+    uint64_t *dbg_masks;     // optional [B][16]: per-round ballot of "loud" frames (diagnostics)
+};
+
+struct MfccArgs {
+    const uint16_t *pcm;
+    uint64_t pcm_stride;
+    uint32_t B;
+    uint32_t max_frames;
+    const sr_vad_rec *vad;  // segment 0 + mid_val + frm_num per utterance
+    int16_t *mfcc;          // [B][max_frames][12]
+    uint32_t tiles;         // frame tiles per utterance
+    uint32_t n_items;       // B * tiles
+    DevTables t;
+};
+
+struct DtwArgs {
+    const int16_t *mfcc;      // [B][max_frames][12]
+    const sr_vad_rec *vad;    // frm_num / status per utterance (or NULL with in_frames)
+    const uint32_t *in_frames;  // optional [B] explicit frame counts (stage-level API)
+    uint32_t B;
+    uint32_t max_frames;
+    const int16_t *tpl;       // [K][tpl_stride]
+    const uint32_t *tpl_frames;
+    const uint8_t *tpl_valid;
+    uint32_t K;
+    uint32_t tpl_stride;      // int16 elements per template
+    uint32_t tpl_rows;        // rows allocated per template
+    uint32_t *scores;         // [B][K]
+    sr_result *results;       // [B] (argmin kernel)
+};
+
+void launch_vad(const VadArgs &a, hipStream_t s);
+void launch_mfcc(const MfccArgs &a, hipStream_t s);
+void launch_dtw(const DtwArgs &a, hipStream_t s);
+void launch_argmin(const DtwArgs &a, hipStream_t s);
+// generic complex 1024-point Q15 FFT, n arrays (cr4_fft_1024_stm32 semantics)
+void launch_fft_q15(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
+// magnitude*10 of bins 0..511 of zero-padded real frames: fft() of MFCC.C:27-62.
+// frames: [n][160] int16; mag: [n][512]; also writes raw FFT words of bins 512..1023 to raw_hi if non-null
+void launch_fft_mag(const int16_t *frames, uint32_t len, uint32_t *mag, uint32_t *raw_hi, uint32_t n,
+                    const DevTables &t, hipStream_t s);
+// get_dis (DTW.C:45-62) for n frame pairs
+void launch_get_dis(const int16_t *a, const int16_t *b, uint32_t *out, uint32_t n, hipStream_t s);
+// dtw_limit (DTW.C:76-109) for n points with explicit statics
+void launch_dtw_limit(const uint16_t *xy, uint8_t *out, uint32_t n, int X1, int X2, int in_n, int mdl_n, hipStream_t s);
+
+}  // namespace sr

@@ -1,0 +1,671 @@
+// Host side of the C ABI declared in include/sr_engine.h: device tables, template store, staging
+// buffers, kernel sequencing on a HIP stream.  No CPU implementation of the recognition path exists
+// in this library; every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sr_device.h"
+#include "sr_tables.h"
+
+namespace sr {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(SR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int reserve(size_t count)
+    {
+        if (count <= n) return SR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) return fail(SR_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        n = count;
+        return SR_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace sr
+
+using namespace sr;
+
+struct sr_engine {
+    sr_config cfg;
+    int device = 0;
+    uint32_t noise_len = 0, atap_frm = 0;
+    HostTables host;
+    DevTables dev{};
+    void *table_blob = nullptr;
+    // template store, dense layout in HBM
+    DevBuf<int16_t> tpl;
+    DevBuf<uint32_t> tpl_frames;
+    DevBuf<uint8_t> tpl_valid;
+    uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
+    // scratch used when the caller does not ask for an intermediate (or passes host buffers)
+    DevBuf<uint16_t> s_pcm;
+    DevBuf<sr_vad_rec> s_vad;
+    DevBuf<int16_t> s_mfcc;
+    DevBuf<uint32_t> s_scores;
+    DevBuf<sr_result> s_results;
+    DevBuf<uint32_t> s_u32a, s_u32b;
+    DevBuf<sr_atap> s_atap;
+    // profiling: one set of 5 events per profiled call since the last sr_set_profiling(h, 1)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;  // 5 per call
+    size_t ev_used = 0;          // calls recorded
+};
+
+static int check_device(int want, int *out_dev)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SR_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count 0"));
+    int dev = want;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= n) return fail(SR_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(SR_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SR_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    *out_dev = dev;
+    return SR_OK;
+}
+
+extern "C" {
+
+const char *sr_last_error(void) { return g_err.c_str(); }
+
+void sr_default_config(sr_config *c)
+{
+    c->fs = 8000;
+    c->frame_time_ms = 20;
+    c->frame_mov_ms = 10;
+    c->nfft = 1024;
+    c->n_mel = 24;
+    c->n_coef = 12;
+    c->max_frames = 119;
+    c->noise_len_ms = 300;
+    c->max_seg = 3;
+    c->device = -1;
+}
+
+int sr_create(const sr_config *cfg, sr_engine **out)
+{
+    if (!cfg || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    // The kernels are specialised for the reference's framing (see sr_tables.h); other sample
+    // rates / FFT sizes are the "extension" configuration and are not built yet.
+    if (cfg->fs != 8000 || cfg->frame_time_ms != 20 || cfg->frame_mov_ms != 10 || cfg->nfft != 1024 ||
+        cfg->n_mel != 24 || cfg->n_coef != 12)
+        return fail(SR_ERR_BAD_CONFIG, "only fs=8000, 20/10 ms framing, nfft=1024, 24 Mel, 12 MFCC is supported");
+    if (cfg->max_frames < 2 || cfg->max_frames > 16383) return fail(SR_ERR_BAD_CONFIG, "max_frames must be 2..16383");
+    if (cfg->max_seg < 1 || cfg->max_seg > SR_MAX_SEG) return fail(SR_ERR_BAD_CONFIG, "max_seg must be 1..3");
+    const uint32_t noise_len = (cfg->fs / 1000) * cfg->noise_len_ms, atap_frm = (cfg->fs / 1000) * 30;
+    if (noise_len == 0 || noise_len % atap_frm != 0 || noise_len % kFrameLen != 0)
+        return fail(SR_ERR_BAD_CONFIG, "noise_len_ms must be a non-zero multiple of 60 ms");
+    int dev = 0;
+    int rc = check_device(cfg->device, &dev);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(dev));
+
+    sr_engine *h = new sr_engine();
+    h->cfg = *cfg;
+    h->device = dev;
+    h->noise_len = noise_len;
+    h->atap_frm = atap_frm;
+    build_tables(h->host);
+    // one blob, 16-byte aligned sub-tables
+    const HostTables &t = h->host;
+    struct Part {
+        const void *src;
+        size_t bytes;
+        size_t off;
+    } parts[8] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
+                  {t.tri_odd.data(), t.tri_odd.size() * 2, 0}, {t.tri_cen.data(), t.tri_cen.size() * 2, 0},
+                  {t.dct.data(), t.dct.size(), 0},             {t.tw_a.data(), t.tw_a.size() * 4, 0},
+                  {t.tw_b.data(), t.tw_b.size() * 4, 0},       {t.log_thr.data(), t.log_thr.size() * 4, 0}};
+    size_t total = 0;
+    for (auto &p : parts) {
+        p.off = total;
+        total += (p.bytes + 255) & ~(size_t)255;
+    }
+    std::vector<uint8_t> blob(total, 0);
+    for (auto &p : parts) std::memcpy(blob.data() + p.off, p.src, p.bytes);
+    hipError_t e = hipMalloc(&h->table_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(h->table_blob, blob.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(SR_ERR_HIP, std::string("table upload: ") + hipGetErrorString(e));
+    }
+    uint8_t *base = (uint8_t *)h->table_blob;
+    h->dev.hamm = (const uint16_t *)(base + parts[0].off);
+    h->dev.tri_even = (const uint16_t *)(base + parts[1].off);
+    h->dev.tri_odd = (const uint16_t *)(base + parts[2].off);
+    h->dev.tri_cen = (const uint16_t *)(base + parts[3].off);
+    h->dev.dct = (const int8_t *)(base + parts[4].off);
+    h->dev.tw_a = (const uint32_t *)(base + parts[5].off);
+    h->dev.tw_b = (const uint32_t *)(base + parts[6].off);
+    h->dev.log_thr = (const uint32_t *)(base + parts[7].off);
+    *out = h;
+    return SR_OK;
+}
+
+void sr_destroy(sr_engine *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->table_blob) (void)hipFree(h->table_blob);
+    h->tpl.release();
+    h->tpl_frames.release();
+    h->tpl_valid.release();
+    h->s_pcm.release();
+    h->s_vad.release();
+    h->s_mfcc.release();
+    h->s_scores.release();
+    h->s_results.release();
+    h->s_u32a.release();
+    h->s_u32b.release();
+    h->s_atap.release();
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+uint32_t sr_num_templates(const sr_engine *h) { return h ? h->K : 0; }
+
+// ---- template store -------------------------------------------------------------------------------
+static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const std::vector<uint32_t> &f,
+                            const std::vector<uint8_t> &v, uint32_t K, uint32_t rows)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->tpl.reserve(m.size()))) return rc;
+    if ((rc = h->tpl_frames.reserve(K))) return rc;
+    if ((rc = h->tpl_valid.reserve(K))) return rc;
+    HIP_TRY(hipMemcpy(h->tpl.p, m.data(), m.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tpl_frames.p, f.data(), K * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tpl_valid.p, v.data(), K, hipMemcpyHostToDevice));
+    h->K = K;
+    h->tpl_rows = rows;
+    h->tpl_stride = rows * kCoef;
+    return SR_OK;
+}
+
+int sr_set_templates_dense(sr_engine *h, const int16_t *mfcc, const uint32_t *frames, const uint8_t *valid,
+                           uint32_t K, uint32_t tpl_stride)
+{
+    if (!h || !mfcc || !frames || K == 0) return fail(SR_ERR_BAD_ARG, "null/empty template set");
+    if (tpl_stride % kCoef) return fail(SR_ERR_BAD_ARG, "tpl_stride must be a multiple of n_coef");
+    const uint32_t src_rows = tpl_stride / kCoef;
+    uint32_t maxf = 1;
+    for (uint32_t k = 0; k < K; k++) {
+        if (frames[k] > src_rows) return fail(SR_ERR_BAD_ARG, "template frame count exceeds its stride");
+        if (frames[k] > 16383) return fail(SR_ERR_BAD_ARG, "template longer than 16383 frames");
+        maxf = frames[k] > maxf ? frames[k] : maxf;
+    }
+    // one row of slack: the do-while of DTW.C:150-154 reads row 1 of a 1-frame template
+    const uint32_t rows = maxf + 1;
+    std::vector<int16_t> m((size_t)K * rows * kCoef, 0);
+    std::vector<uint32_t> f(frames, frames + K);
+    std::vector<uint8_t> v(K, 1);
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t copy_rows = src_rows < rows ? src_rows : rows;
+        std::memcpy(&m[(size_t)k * rows * kCoef], mfcc + (size_t)k * tpl_stride, (size_t)copy_rows * kCoef * 2);
+        if (valid) v[k] = valid[k] ? 1 : 0;
+    }
+    return upload_templates(h, m, f, v, K, rows);
+}
+
+int sr_set_templates(sr_engine *h, const void *store, uint32_t n_slots, uint32_t stride_bytes)
+{
+    if (!h || !store || n_slots == 0) return fail(SR_ERR_BAD_ARG, "null/empty template store");
+    if (stride_bytes < 4 + 2 * kCoef) return fail(SR_ERR_BAD_ARG, "slot stride too small for a v_ftr_tag");
+    // v_ftr_tag image: u16 save_sign | u16 frm_num | s16 mfcc_dat[] (MFCC.H:18-25), slot stride Flash.H:13
+    const uint8_t *s = (const uint8_t *)store;
+    const uint32_t slot_rows = (stride_bytes - 4) / (2 * kCoef);
+    std::vector<uint32_t> f(n_slots);
+    std::vector<uint8_t> v(n_slots);
+    uint32_t maxf = 1;
+    for (uint32_t k = 0; k < n_slots; k++) {
+        uint16_t sign, fr;
+        std::memcpy(&sign, s + (size_t)k * stride_bytes, 2);
+        std::memcpy(&fr, s + (size_t)k * stride_bytes + 2, 2);
+        v[k] = sign == SR_SAVE_MASK;
+        f[k] = fr;
+        if (v[k]) {
+            if (fr > slot_rows) return fail(SR_ERR_BAD_ARG, "slot frm_num exceeds the slot size");
+            maxf = fr > maxf ? fr : maxf;
+        }
+    }
+    uint32_t rows = maxf + 1;
+    std::vector<int16_t> m((size_t)n_slots * rows * kCoef, 0);
+    for (uint32_t k = 0; k < n_slots; k++) {
+        if (!v[k]) continue;
+        const uint32_t copy_rows = slot_rows < rows ? slot_rows : rows;  // keeps whatever follows frm_num rows
+        std::memcpy(&m[(size_t)k * rows * kCoef], s + (size_t)k * stride_bytes + 4, (size_t)copy_rows * kCoef * 2);
+    }
+    return upload_templates(h, m, f, v, n_slots, rows);
+}
+
+// ---- profiling ------------------------------------------------------------------------------------
+int sr_set_profiling(sr_engine *h, int on)
+{
+    if (!h) return fail(SR_ERR_BAD_ARG, "null engine");
+    HIP_TRY(hipSetDevice(h->device));
+    h->profiling = on != 0;
+    h->ev_used = 0;
+    return SR_OK;
+}
+
+int sr_get_stage_ms(sr_engine *h, float ms[5])
+{
+    if (!h || !ms) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->ev_used) return fail(SR_ERR_BAD_ARG, "no profiled call recorded");
+    // averages over every call recorded since profiling was switched on
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (size_t c = 0; c < h->ev_used; c++) {
+        hipEvent_t *e = &h->ev[5 * c];
+        HIP_TRY(hipEventSynchronize(e[4]));
+        float t;
+        for (int i = 0; i < 4; i++) {
+            HIP_TRY(hipEventElapsedTime(&t, e[i], e[i + 1]));
+            acc[i] += t;
+        }
+        HIP_TRY(hipEventElapsedTime(&t, e[0], e[4]));
+        acc[4] += t;
+    }
+    for (int i = 0; i < 5; i++) ms[i] = (float)(acc[i] / (double)h->ev_used);
+    return SR_OK;
+}
+
+// ---- device-resident pipeline ---------------------------------------------------------------------
+static int check_pcm(const sr_engine *h, const uint16_t *pcm, uint64_t stride, uint32_t buf_len)
+{
+    if (!pcm) return fail(SR_ERR_BAD_ARG, "null pcm");
+    if (((uintptr_t)pcm & 15) || (stride & 7)) return fail(SR_ERR_BAD_ARG, "pcm must be 16-byte aligned, stride % 8 == 0");
+    if (buf_len > stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    if (buf_len < h->noise_len || buf_len <= (uint32_t)kFrameLen) return fail(SR_ERR_BAD_ARG, "buf_len shorter than the noise head");
+    if (buf_len > 0x7FFFFFF0u) return fail(SR_ERR_BAD_ARG, "buf_len too large");
+    return SR_OK;
+}
+
+int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                     sr_vad_rec *d_vad, void *stream)
+{
+    if (!h || !d_vad) return fail(SR_ERR_BAD_ARG, "null argument");
+    int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    VadArgs a{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr};
+    launch_vad(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t B,
+                          const sr_vad_rec *d_vad, int16_t *d_mfcc)
+{
+    MfccArgs a;
+    a.pcm = d_pcm;
+    a.pcm_stride = pcm_stride;
+    a.B = B;
+    a.max_frames = h->cfg.max_frames;
+    a.vad = d_vad;
+    a.mfcc = d_mfcc;
+    a.tiles = (h->cfg.max_frames + 31) / 32;
+    a.n_items = B * a.tiles;
+    a.t = h->dev;
+    return a;
+}
+
+int sr_mfcc_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t B, const sr_vad_rec *d_vad,
+                      int16_t *d_mfcc, void *stream)
+{
+    if (!h || !d_pcm || !d_vad || !d_mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
+    if ((uint64_t)B * ((h->cfg.max_frames + 31) / 32) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
+    HIP_TRY(hipSetDevice(h->device));
+    launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, d_vad, d_mfcc), (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_vad, const uint32_t *d_in_frames,
+                        uint32_t B, uint32_t *d_scores, sr_result *d_results)
+{
+    DtwArgs a;
+    a.mfcc = d_mfcc;
+    a.vad = d_vad;
+    a.in_frames = d_in_frames;
+    a.B = B;
+    a.max_frames = h->cfg.max_frames;
+    a.tpl = h->tpl.p;
+    a.tpl_frames = h->tpl_frames.p;
+    a.tpl_valid = h->tpl_valid.p;
+    a.K = h->K;
+    a.tpl_stride = h->tpl_stride;
+    a.tpl_rows = h->tpl_rows;
+    a.scores = d_scores;
+    a.results = d_results;
+    return a;
+}
+
+int sr_dtw_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_vad, uint32_t B, uint32_t *d_scores,
+                     sr_result *d_results, void *stream)
+{
+    if (!h || !d_mfcc || !d_vad || !d_scores) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    HIP_TRY(hipSetDevice(h->device));
+    DtwArgs a = dtw_args(h, d_mfcc, d_vad, nullptr, B, d_scores, d_results);
+    launch_dtw(a, (hipStream_t)stream);
+    if (d_results) launch_argmin(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                           sr_result *d_results, uint32_t *d_scores, int16_t *d_mfcc, sr_vad_rec *d_vad, void *stream)
+{
+    if (!h || !d_results) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if (B == 0) return SR_OK;
+    int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
+    if (rc) return rc;
+    if ((uint64_t)B * ((h->cfg.max_frames + 31) / 32) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_vad) {
+        if ((rc = h->s_vad.reserve(B))) return rc;
+        d_vad = h->s_vad.p;
+    }
+    if (!d_mfcc) {
+        if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+        d_mfcc = h->s_mfcc.p;
+    }
+    if (!d_scores) {
+        if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
+        d_scores = h->s_scores.p;
+    }
+    const bool prof = h->profiling;
+    hipEvent_t *ev = nullptr;
+    if (prof) {
+        while (h->ev.size() < 5 * (h->ev_used + 1)) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        ev = &h->ev[5 * h->ev_used];
+    }
+    VadArgs va{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr};
+    if (prof) HIP_TRY(hipEventRecord(ev[0], s));
+    launch_vad(va, s);
+    if (prof) HIP_TRY(hipEventRecord(ev[1], s));
+    launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, d_vad, d_mfcc), s);
+    if (prof) HIP_TRY(hipEventRecord(ev[2], s));
+    DtwArgs da = dtw_args(h, d_mfcc, d_vad, nullptr, B, d_scores, d_results);
+    launch_dtw(da, s);
+    if (prof) HIP_TRY(hipEventRecord(ev[3], s));
+    launch_argmin(da, s);
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev[4], s));
+        h->ev_used++;
+    }
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+// ---- host-buffer wrappers (stage through HBM) --------------------------------------------------------
+static int stage_pcm(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                     uint64_t *dev_stride)
+{
+    const uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
+    int rc = h->s_pcm.reserve((size_t)B * ds);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2D(h->s_pcm.p, ds * 2, pcm, pcm_stride * 2, (size_t)buf_len * 2, B, hipMemcpyHostToDevice));
+    *dev_stride = ds;
+    return SR_OK;
+}
+
+int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                       sr_result *results, uint32_t *scores, int16_t *mfcc, sr_vad_rec *vad)
+{
+    if (!h || !pcm || !results) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if (B == 0) return SR_OK;
+    if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_results.reserve(B))) return rc;
+    if ((rc = h->s_vad.reserve(B))) return rc;
+    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+    if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
+    rc = sr_recognize_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_results.p, h->s_scores.p, h->s_mfcc.p, h->s_vad.p,
+                                nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(results, h->s_results.p, (size_t)B * sizeof(sr_result), hipMemcpyDeviceToHost));
+    if (scores) HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
+    if (mfcc)
+        HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * kCoef * 2, hipMemcpyDeviceToHost));
+    if (vad) HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_vad_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B, sr_vad_rec *vad)
+{
+    if (!h || !pcm || !vad) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (B == 0) return SR_OK;
+    if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_vad.reserve(B))) return rc;
+    if ((rc = sr_vad_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_vad.p, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// diagnostics: per-utterance ballots of the "loud" decision (VAD.C:164), 63 frames per 64-bit word
+int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                       sr_vad_rec *vad, uint64_t *masks /* [B][16] */)
+{
+    if (!h || !pcm || !vad || !masks) return fail(SR_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_vad.reserve(B))) return rc;
+    DevBuf<uint64_t> dm;
+    if ((rc = dm.reserve((size_t)B * 16))) return rc;
+    HIP_TRY(hipMemset(dm.p, 0, (size_t)B * 16 * 8));
+    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, h->s_vad.p, nullptr, dm.p};
+    launch_vad(a, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(masks, dm.p, (size_t)B * 16 * 8, hipMemcpyDeviceToHost));
+    dm.release();
+    return SR_OK;
+}
+
+int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                  const int32_t *start, const int32_t *end, const uint32_t *mid, int16_t *mfcc, uint32_t *frm_num)
+{
+    if (!h || !pcm || !start || !end || !mid || !mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (B == 0) return SR_OK;
+    if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    HIP_TRY(hipSetDevice(h->device));
+    // build the per-utterance records the frame kernel consumes (what k_vad would have produced)
+    std::vector<sr_vad_rec> recs(B);
+    for (uint32_t b = 0; b < B; b++) {
+        sr_vad_rec &r = recs[b];
+        std::memset(&r, 0, sizeof r);
+        r.atap.mid_val = mid[b];
+        for (int i = 0; i < 2 * SR_MAX_SEG; i++) r.seg[i] = -1;
+        r.seg[0] = start[b];
+        r.seg[1] = end[b];
+        if (start[b] < 1 || end[b] > (int32_t)buf_len || end[b] - start[b] < kFrameLen)
+            return fail(SR_ERR_BAD_ARG, "segment outside the buffer (start must be >= 1: MFCC.C:119 reads start[-1])");
+        const uint32_t n = ((((uint32_t)(end[b] - start[b]) - kFrameLen) / kHop) + 1) & 0xFFFF;  // MFCC.C:102
+        r.status = n > h->cfg.max_frames ? SR_ST_MFCC_FAIL : SR_ST_OK;                           // MFCC.C:103-107
+        r.frm_num = n > h->cfg.max_frames ? 0 : n;
+        if (frm_num) frm_num[b] = r.frm_num;
+    }
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_vad.reserve(B))) return rc;
+    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+    HIP_TRY(hipMemcpy(h->s_vad.p, recs.data(), (size_t)B * sizeof(sr_vad_rec), hipMemcpyHostToDevice));
+    if ((rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, B, h->s_vad.p, h->s_mfcc.p, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * kCoef * 2, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores,
+                 sr_result *results)
+{
+    if (!h || !in_mfcc || !in_frames || !scores) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if (B == 0) return SR_OK;
+    for (uint32_t b = 0; b < B; b++)
+        if (in_frames[b] > h->cfg.max_frames) return fail(SR_ERR_BAD_ARG, "in_frames exceeds max_frames");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
+    if ((rc = h->s_mfcc.reserve(msz))) return rc;
+    if ((rc = h->s_u32a.reserve(B))) return rc;
+    if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
+    if ((rc = h->s_results.reserve(B))) return rc;
+    HIP_TRY(hipMemcpy(h->s_mfcc.p, in_mfcc, msz * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->s_u32a.p, in_frames, (size_t)B * 4, hipMemcpyHostToDevice));
+    DtwArgs a = dtw_args(h, h->s_mfcc.p, nullptr, h->s_u32a.p, B, h->s_scores.p, h->s_results.p);
+    launch_dtw(a, nullptr);
+    launch_argmin(a, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
+    if (results) HIP_TRY(hipMemcpy(results, h->s_results.p, (size_t)B * sizeof(sr_result), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    if (!h || !in || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (n == 0) return SR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->s_u32a.reserve((size_t)n * kNfft))) return rc;
+    if ((rc = h->s_u32b.reserve((size_t)n * kNfft))) return rc;
+    HIP_TRY(hipMemcpy(h->s_u32a.p, in, (size_t)n * kNfft * 4, hipMemcpyHostToDevice));
+    launch_fft_q15(h->s_u32a.p, h->s_u32b.p, n, h->dev, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, h->s_u32b.p, (size_t)n * kNfft * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+}  // extern "C"
+
+// internal hooks for sr_compat.cpp
+namespace sr {
+int engine_fft_mag(sr_engine *h, const int16_t *frame, uint32_t len, uint32_t *mag, uint32_t *raw_hi)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->s_mfcc.reserve(len > 0 ? len : 1))) return rc;
+    if ((rc = h->s_u32a.reserve(kBins))) return rc;
+    if ((rc = h->s_u32b.reserve(kBins))) return rc;
+    if (len) HIP_TRY(hipMemcpy(h->s_mfcc.p, frame, (size_t)len * 2, hipMemcpyHostToDevice));
+    launch_fft_mag(h->s_mfcc.p, len, h->s_u32a.p, h->s_u32b.p, 1, h->dev, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(mag, h->s_u32a.p, kBins * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(raw_hi, h->s_u32b.p, kBins * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int engine_get_dis(sr_engine *h, const int16_t *a, const int16_t *b, uint32_t *out)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->s_mfcc.reserve(2 * kCoef))) return rc;
+    if ((rc = h->s_u32a.reserve(1))) return rc;
+    HIP_TRY(hipMemcpy(h->s_mfcc.p, a, kCoef * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->s_mfcc.p + kCoef, b, kCoef * 2, hipMemcpyHostToDevice));
+    launch_get_dis(h->s_mfcc.p, h->s_mfcc.p + kCoef, h->s_u32a.p, 1, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, h->s_u32a.p, 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int engine_dtw_limit(sr_engine *h, uint16_t x, uint16_t y, int X1, int X2, int in_n, int mdl_n, uint8_t *out)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->s_u32a.reserve(2))) return rc;
+    const uint16_t xy[2] = {x, y};
+    HIP_TRY(hipMemcpy(h->s_u32a.p, xy, 4, hipMemcpyHostToDevice));
+    launch_dtw_limit((const uint16_t *)h->s_u32a.p, (uint8_t *)(h->s_u32a.p + 1), 1, X1, X2, in_n, mdl_n, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, h->s_u32a.p + 1, 1, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, const sr_atap *atap, sr_vad_rec *rec)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, pcm, buf_len, buf_len, 1, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_vad.reserve(1))) return rc;
+    if ((rc = h->s_atap.reserve(1))) return rc;
+    HIP_TRY(hipMemcpy(h->s_atap.p, atap, sizeof(sr_atap), hipMemcpyHostToDevice));
+    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, h->s_atap.p, nullptr};
+    launch_vad(a, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rec, h->s_vad.p, sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// noise_atap alone: run the VAD kernel on the noise head only (buf_len = n_len gives F frames of no
+// interest; only the atap part of the record is used)
+int engine_noise_atap(sr_engine *h, const uint16_t *noise, uint32_t n_len, sr_atap *out)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, noise, n_len, n_len, 1, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_vad.reserve(1))) return rc;
+    VadArgs a{h->s_pcm.p, ds, n_len, n_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, nullptr, nullptr};
+    launch_vad(a, nullptr);
+    HIP_TRY(hipGetLastError());
+    sr_vad_rec rec;
+    HIP_TRY(hipMemcpy(&rec, h->s_vad.p, sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+    *out = rec.atap;
+    return SR_OK;
+}
+}  // namespace sr

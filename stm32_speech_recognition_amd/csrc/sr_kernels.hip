@@ -1,0 +1,885 @@
+// HIP kernels for gfx950 (MI355X, CDNA4).  Wave = 64 lanes everywhere; no MFMA (the path has no
+// dense contraction), integer VALU + LDS.  Every kernel reproduces the reference's integer
+// arithmetic bit for bit; the cited lines are relative to the reference tree.
+//
+//   k_vad     noise_atap (VAD.C:22-71) + VAD (VAD.C:97-218) + frame count of get_mfcc (MFCC.C:102-107)
+//   k_mfcc    get_mfcc (MFCC.C:86-191) incl. fft (MFCC.C:27-62) and cr4_fft_1024_stm32 (.s:95-281)
+//   k_dtw     dtw / get_dis / dtw_limit (DTW.C:45-192) for every (utterance, template) pair
+//   k_argmin  the template scan of spch_recg (main.c:276-295)
+#include "sr_device.h"
+#include "sr_tables.h"
+
+namespace sr {
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
+{
+    // v_dot2_i32_i16: a.lo*b.lo + a.hi*b.hi + c, signed 16-bit halves, 32-bit wrap
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
+}
+__device__ __forceinline__ int sext_lo(uint32_t w) { return (int)(short)(w & 0xFFFFu); }
+__device__ __forceinline__ int sext_hi(uint32_t w) { return (int)w >> 16; }
+__device__ __forceinline__ uint32_t pack16(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
+
+// Orders LDS traffic between lanes of ONE wave: DS instructions of a wave execute in issue order, so
+// only the compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// DPP row shifts: lane i takes the value of lane i-N inside its row of 16, 0 when there is none.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive prefix sum over the 64 lanes of a wave (u32 wrap)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    v += dpp_take<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_take<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_take<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_take<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_take<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q15 radix-4 butterfly of the ST FFT (cr4_fft_1024_stm32.s)
+// ------------------------------------------------------------------------------------------------
+// CXMUL_V7 (.s:95-102): Y*conj(K), Q14.  The asm's 3-multiply form equals, in the ring of 32-bit
+// integers, re = Yr*Kc + Yi*Ks, im = Yi*Kc - Yr*Ks with Kc = Kr'+Ki, Ks = Ki (no term overflows).
+__device__ __forceinline__ void cxmul(uint32_t y, uint32_t ka, uint32_t kb, int &re, int &im)
+{
+    re = sdot2(y, ka, 0);
+    im = sdot2(y, kb, 0);
+}
+
+// CXADDA4 (.s:105-129, S = 14) and the combine of BUTFLY4ZERO_OPT (.s:147-168, S = 0).
+// In: A (sign-extended sample), B, C, D (products or samples).  Out as stored by the asm:
+//   x[j] = (ar, ai)   x[j+q] = (br, bi)   x[j+2q] = (cr, ci)   x[j+3q] = (di, dr)   <- "inversion"
+template <int S>
+__device__ __forceinline__ void r4_combine(int &ar, int &ai, int &br, int &bi, int &cr, int &ci, int &dr, int &di)
+{
+    int tr = cr + dr, ti = ci + di;  // (C,D) = (C+D, C-D)
+    dr = cr - dr;
+    di = ci - di;
+    cr = tr;
+    ci = ti;
+    ar >>= 2;
+    ai >>= 2;
+    ar += br >> (2 + S);
+    ai += bi >> (2 + S);
+    br = ar - (br >> (1 + S));
+    bi = ai - (bi >> (1 + S));
+    ar += cr >> (2 + S);
+    ai += ci >> (2 + S);
+    cr = ar - (cr >> (1 + S));
+    ci = ai - (ci >> (1 + S));
+    br += di >> (2 + S);
+    bi -= dr >> (2 + S);
+    di = br - (di >> (1 + S));
+    dr = bi + (dr >> (1 + S));
+}
+
+// One twiddled butterfly on packed words; k* = packed coefficient pairs for the legs j+q, j+2q, j+3q.
+// Results are re-packed to 16+16 bits, which is the STRH truncation of .s:194-204.
+__device__ __forceinline__ void bfly(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, uint32_t k1a, uint32_t k1b,
+                                     uint32_t k2a, uint32_t k2b, uint32_t k3a, uint32_t k3b)
+{
+    int ar = sext_lo(x0), ai = sext_hi(x0), br, bi, cr, ci, dr, di;
+    cxmul(x3, k3a, k3b, dr, di);
+    cxmul(x2, k2a, k2b, cr, ci);
+    cxmul(x1, k1a, k1b, br, bi);
+    r4_combine<14>(ar, ai, br, bi, cr, ci, dr, di);
+    x0 = pack16(ar, ai);
+    x1 = pack16(br, bi);
+    x2 = pack16(cr, ci);
+    x3 = pack16(di, dr);
+}
+
+__device__ __forceinline__ int rev2(int d) { return ((d & 1) << 1) | (d >> 1); }
+
+// LDS image of the 1024-point work array between passes 3 and 4: word j lives at j + 4*(j>>6).
+// With lane = d0 + 4*d3 + 16*d4 writing j = d0 + 4*d1 + 16*d2 + 64*d3 + 256*d4 the 32 lanes of a
+// ds_write_b32 group hit 32 distinct banks; reads by lane = j & 63 are consecutive words.
+__device__ __forceinline__ int xaddr(int j) { return j + ((j >> 6) << 2); }
+constexpr int kXchgWords = 1024 + 4 * 16;  // 1088
+
+// Coefficients a lane needs, all lane-invariant across frames -> loaded once per wave into VGPRs.
+struct LaneTw {
+    uint32_t s2[2][2];     // pass 2 (q=4):   legs j+q, j+2q (j+3q is always zero-padding)
+    uint32_t s3[4][3][2];  // pass 3 (q=16):  per d1, legs j+q, j+2q, j+3q
+    uint32_t s4[3][2];     // pass 4 (q=64)
+    uint32_t s5[4][3][2];  // pass 5 (q=256): per d3
+};
+
+// Table entry order per butterfly is (leg j+3q, leg j+2q, leg j+q)  (.s:182-191).
+__device__ __forceinline__ void load_tw3(const DevTables &t, int base, int b, uint32_t (&k)[3][2])
+{
+    const int e = base + 3 * b;
+    k[0][0] = t.tw_a[e + 2];
+    k[0][1] = t.tw_b[e + 2];  // leg j+q
+    k[1][0] = t.tw_a[e + 1];
+    k[1][1] = t.tw_b[e + 1];  // leg j+2q
+    k[2][0] = t.tw_a[e + 0];
+    k[2][1] = t.tw_b[e + 0];  // leg j+3q
+}
+
+__device__ __forceinline__ void load_lane_tw(const DevTables &t, int lane, LaneTw &tw)
+{
+    const int d0 = lane & 3;
+    {
+        uint32_t k[3][2];
+        load_tw3(t, 0, d0, k);
+        tw.s2[0][0] = k[0][0];
+        tw.s2[0][1] = k[0][1];
+        tw.s2[1][0] = k[1][0];
+        tw.s2[1][1] = k[1][1];
+    }
+#pragma unroll
+    for (int d1 = 0; d1 < 4; d1++) load_tw3(t, 12, d0 + 4 * d1, tw.s3[d1]);
+    load_tw3(t, 60, lane, tw.s4);
+#pragma unroll
+    for (int d3 = 0; d3 < 4; d3++) load_tw3(t, 252, lane + 64 * d3, tw.s5[d3]);
+}
+
+// Passes 1-3 for the zero-padded real frame that get_mfcc feeds (MFCC.C:37-47): only x[0..159] are
+// non-zero and every imaginary part is 0.  Pass 1 (.s:226-232) then degenerates exactly to
+// out[4*idx+k] = x[bitrev8(idx)] >> 2 (k = 0..3), so it is folded into the gather.
+// lane = d0 + 4*d3 + 16*d4 ; v[d1][d2] <-> j = d0 + 4*d1 + 16*d2 + 64*d3 + 256*d4.
+__device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const LaneTw &tw, uint32_t (&v)[4][4])
+{
+    const int d3 = (lane >> 2) & 3, d4 = lane >> 4;
+    const int base = rev2(d4) + 4 * rev2(d3);
+    // bitrev8(j>>2) = base + 16*rev2(d2) + 64*rev2(d1); >= 160 <=> zero padding
+    uint32_t y[10];
+#pragma unroll
+    for (int m = 0; m < 10; m++) y[m] = (uint32_t)(xw[base + 16 * m] >> 2) & 0xFFFFu;
+#pragma unroll
+    for (int d2 = 0; d2 < 4; d2++) {
+        const int r2 = ((d2 & 1) << 1) | (d2 >> 1);
+        uint32_t x0 = y[r2];                                      // d1 = 0 -> rows   0..63
+        uint32_t x2 = y[4 + r2];                                  // d1 = 2 -> rows  64..127
+        uint32_t x1 = (d2 == 0) ? y[8] : (d2 == 2) ? y[9] : 0u;   // d1 = 1 -> rows 128..159, else padding
+        uint32_t x3 = 0u;                                         // d1 = 3 -> rows >= 192: padding
+        int ar = sext_lo(x0), ai = 0, br = 0, bi = 0, cr, ci, dr = 0, di = 0;
+        cxmul(x2, tw.s2[1][0], tw.s2[1][1], cr, ci);
+        if (d2 == 0 || d2 == 2) cxmul(x1, tw.s2[0][0], tw.s2[0][1], br, bi);
+        (void)x3;
+        r4_combine<14>(ar, ai, br, bi, cr, ci, dr, di);
+        v[0][d2] = pack16(ar, ai);
+        v[1][d2] = pack16(br, bi);
+        v[2][d2] = pack16(cr, ci);
+        v[3][d2] = pack16(di, dr);
+    }
+#pragma unroll
+    for (int d1 = 0; d1 < 4; d1++)
+        bfly(v[d1][0], v[d1][1], v[d1][2], v[d1][3], tw.s3[d1][0][0], tw.s3[d1][0][1], tw.s3[d1][1][0],
+             tw.s3[d1][1][1], tw.s3[d1][2][0], tw.s3[d1][2][1]);
+}
+
+// lane (d0,d3,d4) -> LDS -> lane' = j & 63 holding u[d3][d4]
+__device__ __forceinline__ void fft_exchange(uint32_t *buf, int lane, const uint32_t (&v)[4][4], uint32_t (&u)[4][4])
+{
+    const int d0 = lane & 3, d3 = (lane >> 2) & 3, d4 = lane >> 4;
+    const int jw = d0 + 64 * d3 + 256 * d4;
+#pragma unroll
+    for (int d1 = 0; d1 < 4; d1++)
+#pragma unroll
+        for (int d2 = 0; d2 < 4; d2++) buf[xaddr(jw + 4 * d1 + 16 * d2)] = v[d1][d2];
+    wave_sync();
+#pragma unroll
+    for (int e3 = 0; e3 < 4; e3++)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; e4++) u[e3][e4] = buf[xaddr(lane + 64 * e3 + 256 * e4)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mfcc
+// ------------------------------------------------------------------------------------------------
+constexpr int kMfccWaves = 4;       // waves per workgroup
+constexpr int kFramesPerWave = 8;   // consecutive frames one wave turns into MFCCs per work item
+constexpr int kFramesPerTile = kMfccWaves * kFramesPerWave;
+// per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
+constexpr int kWaveLdsWords = kXchgWords + kFrameLen + kFramesPerWave * kMel;
+
+// (u32)(log((double)n)*100), MFCC.C:168, as a step function (see sr_tables.cpp gen_log_thr).
+__device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__restrict__ thr)
+{
+    if (n == 0) return 0;  // log(0) = -inf -> 0 (ARM softfp and x86-64 both give 0 for the UB cast)
+    int m = (int)(__log2f((float)n) * 69.31471806f);
+    m = m < 0 ? 0 : (m > kLogMax ? kLogMax : m);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        if (n < thr[m])
+            m -= 1;
+        else if (m < kLogMax && n >= thr[m + 1])
+            m += 1;
+    }
+    return (uint32_t)m;
+}
+
+__global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ int8_t s_dct[kCoef * kMel];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *buf = smem + w * kWaveLdsWords;
+    int *xw = (int *)(buf + kXchgWords);
+    uint32_t *powb = buf + kXchgWords + kFrameLen;
+
+    for (int i = threadIdx.x; i < kCoef * kMel; i += blockDim.x) s_dct[i] = a.t.dct[i];
+    __syncthreads();
+
+    // ---- lane-invariant constants --------------------------------------------------------------
+    LaneTw tw;
+    load_lane_tw(a.t, lane, tw);
+    int hamm_r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
+    uint32_t tri_e[8], tri_o[8];  // triangle weights of bins 8*lane .. 8*lane+7
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        tri_e[k] = a.t.tri_even[8 * lane + k];
+        tri_o[k] = a.t.tri_odd[8 * lane + k];
+    }
+    // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
+    int f_lo = 0, f_hi = 0;
+    if (lane < kMel) {
+        const int h = lane;
+        f_lo = (h == 0) ? 0 : (int)a.t.tri_cen[h - 1];
+        f_hi = (h == kMel - 1) ? kBins : (int)a.t.tri_cen[h + 1];
+    }
+
+    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const uint32_t b = item / a.tiles, tile = item - b * a.tiles;
+        const sr_vad_rec *rec = a.vad + b;
+        const uint32_t nfrm = rec->frm_num;
+        const int mid = (int)rec->atap.mid_val;
+        const int seg0 = rec->seg[0];
+        const uint16_t *row = a.pcm + (uint64_t)b * a.pcm_stride;
+        int16_t *out = a.mfcc + (uint64_t)b * a.max_frames * kCoef;
+        const uint32_t f0 = tile * kFramesPerTile + w * kFramesPerWave;
+        uint32_t nf = 0;  // frames this wave really has
+        if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFramesPerWave) ? nfrm - f0 : (uint32_t)kFramesPerWave;
+
+        for (uint32_t fi = 0; fi < nf; fi++) {
+            const uint16_t *x = row + seg0 + (int)kHop * (int)(f0 + fi);
+            // ---- pre-emphasis + Hamming (MFCC.C:115-124); x[-1] is the sample before the frame
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int i = lane + 64 * k;
+                if (i < kFrameLen) {
+                    const int cur = (int)x[i] - mid, prv = (int)x[i - 1] - mid;
+                    const int t = cur - prv * 95 / 100;
+                    xw[i] = (int)(short)(t * hamm_r[k] / 1000);
+                }
+            }
+            wave_sync();
+            // ---- FFT passes 1-3 in registers, exchange, passes 4-5 in registers
+            uint32_t v[4][4], u[4][4];
+            fft_front_real160(xw, lane, tw, v);
+            fft_exchange(buf, lane, v, u);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; e4++)
+                bfly(u[0][e4], u[1][e4], u[2][e4], u[3][e4], tw.s4[0][0], tw.s4[0][1], tw.s4[1][0], tw.s4[1][1],
+                     tw.s4[2][0], tw.s4[2][1]);
+            // pass 5: only x[j] and x[j+q] (bins < 512) are consumed (MFCC.C:49)
+            wave_sync();
+#pragma unroll
+            for (int e3 = 0; e3 < 4; e3++) {
+                int ar = sext_lo(u[e3][0]), ai = sext_hi(u[e3][0]), br, bi, cr, ci, dr, di;
+                cxmul(u[e3][3], tw.s5[e3][2][0], tw.s5[e3][2][1], dr, di);
+                cxmul(u[e3][2], tw.s5[e3][1][0], tw.s5[e3][1][1], cr, ci);
+                cxmul(u[e3][1], tw.s5[e3][0][0], tw.s5[e3][0][1], br, bi);
+                r4_combine<14>(ar, ai, br, bi, cr, ci, dr, di);
+                // ---- |X|*10 and energy (MFCC.C:49-60, 128-133); (s16) = the STRH truncation
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    const int re = (int)(short)(o ? br : ar), im = (int)(short)(o ? bi : ai);
+                    const int r = re * re + im * im;
+                    const uint32_t mag = (uint32_t)(sqrtf((float)r) * 10.0f);
+                    buf[lane + 64 * e3 + 256 * o] = mag * mag;
+                }
+            }
+            wave_sync();
+            // ---- Mel filterbank as prefix sums over bins (each term /100 before summing, u32 wrap)
+            uint32_t pe[8], po[8];
+            {
+                const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
+                const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                uint32_t se = 0, so = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    se += e[k] * tri_e[k] / 100u;
+                    so += e[k] * tri_o[k] / 100u;
+                    pe[k] = se;
+                    po[k] = so;
+                }
+                const uint32_t xe = wave_scan_incl(se) - se, xo = wave_scan_incl(so) - so;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    pe[k] += xe;
+                    po[k] += xo;
+                }
+            }
+            wave_sync();
+            *(uint4 *)(buf + 8 * lane) = make_uint4(pe[0], pe[1], pe[2], pe[3]);
+            *(uint4 *)(buf + 8 * lane + 4) = make_uint4(pe[4], pe[5], pe[6], pe[7]);
+            *(uint4 *)(buf + kBins + 8 * lane) = make_uint4(po[0], po[1], po[2], po[3]);
+            *(uint4 *)(buf + kBins + 8 * lane + 4) = make_uint4(po[4], po[5], po[6], po[7]);
+            wave_sync();
+            if (lane < kMel) {
+                const uint32_t *P = buf + ((lane & 1) ? kBins : 0);
+                const uint32_t hi = P[f_hi - 1], lo = f_lo ? P[f_lo - 1] : 0u;
+                powb[fi * kMel + lane] = hi - lo;
+            }
+            wave_sync();
+        }
+
+        // ---- log (MFCC.C:165-170) and DCT (MFCC.C:173-183) for the wave's nf frames, all lanes busy
+        for (uint32_t t = lane; t < nf * kMel; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr);
+        wave_sync();
+        for (uint32_t t = lane; t < nf * kCoef; t += 64) {
+            const uint32_t fi = t / kCoef, h = t - fi * kCoef;
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < kMel; i++) acc += (int)powb[fi * kMel + i] * (int)s_dct[h * kMel + i] / 100;
+            out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
+        }
+        wave_sync();
+        // rows >= frm_num of this tile are zeroed so that every row of the output is defined
+        {
+            const uint32_t r0 = f0 + nf, r1 = (f0 + kFramesPerWave < a.max_frames) ? f0 + kFramesPerWave : a.max_frames;
+            for (uint32_t t = r0 * kCoef + lane; t < r1 * kCoef && r0 < r1; t += 64) out[t] = 0;
+        }
+    }
+}
+
+void launch_mfcc(const MfccArgs &a, hipStream_t s)
+{
+    if (a.n_items == 0) return;
+    const uint32_t cap = 256u * 8u;  // persistent-style grid: a few workgroups per CU, items strided
+    const uint32_t grid = a.n_items < cap ? a.n_items : cap;
+    const size_t lds = (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_mfcc, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic complex FFT (cr4_fft_1024_stm32 symbol) and fft() magnitudes: one wave per array
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bitrev8(int v) { return (int)(__brev((uint32_t)v) >> 24); }
+
+// Full-complex passes 1-5, result in natural order in `out` (global).  in/out may not alias in LDS terms.
+__device__ void fft_full_wave(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *buf, int lane,
+                              const DevTables &t)
+{
+    // pass 1 (.s:226-232): 256 butterflies, 4 per lane, bit-reversed gather, legs 256 words apart
+    // loaded in the order A, C, B, D (.s:134-145); outputs to buf[4*idx + k]
+    for (int m = 0; m < 4; m++) {
+        const int idx = lane + 64 * m, r = bitrev8(idx);
+        const uint32_t wa = in[r], wc = in[r + 256], wb = in[r + 512], wd = in[r + 768];
+        int ar = sext_lo(wa), ai = sext_hi(wa), br = sext_lo(wb), bi = sext_hi(wb);
+        int cr = sext_lo(wc), ci = sext_hi(wc), dr = sext_lo(wd), di = sext_hi(wd);
+        r4_combine<0>(ar, ai, br, bi, cr, ci, dr, di);
+        buf[xaddr(4 * idx + 0)] = pack16(ar, ai);
+        buf[xaddr(4 * idx + 1)] = pack16(br, bi);
+        buf[xaddr(4 * idx + 2)] = pack16(cr, ci);
+        buf[xaddr(4 * idx + 3)] = pack16(di, dr);
+    }
+    wave_sync();
+    LaneTw tw;
+    load_lane_tw(t, lane, tw);
+    uint32_t k2[3][2];
+    load_tw3(t, 0, lane & 3, k2);
+    const int d0 = lane & 3, d3 = (lane >> 2) & 3, d4 = lane >> 4;
+    uint32_t v[4][4], u[4][4];
+#pragma unroll
+    for (int d1 = 0; d1 < 4; d1++)
+#pragma unroll
+        for (int d2 = 0; d2 < 4; d2++) v[d1][d2] = buf[xaddr(d0 + 4 * d1 + 16 * d2 + 64 * d3 + 256 * d4)];
+    wave_sync();
+#pragma unroll
+    for (int d2 = 0; d2 < 4; d2++)
+        bfly(v[0][d2], v[1][d2], v[2][d2], v[3][d2], k2[0][0], k2[0][1], k2[1][0], k2[1][1], k2[2][0], k2[2][1]);
+#pragma unroll
+    for (int d1 = 0; d1 < 4; d1++)
+        bfly(v[d1][0], v[d1][1], v[d1][2], v[d1][3], tw.s3[d1][0][0], tw.s3[d1][0][1], tw.s3[d1][1][0],
+             tw.s3[d1][1][1], tw.s3[d1][2][0], tw.s3[d1][2][1]);
+    fft_exchange(buf, lane, v, u);
+#pragma unroll
+    for (int e4 = 0; e4 < 4; e4++)
+        bfly(u[0][e4], u[1][e4], u[2][e4], u[3][e4], tw.s4[0][0], tw.s4[0][1], tw.s4[1][0], tw.s4[1][1], tw.s4[2][0],
+             tw.s4[2][1]);
+#pragma unroll
+    for (int e3 = 0; e3 < 4; e3++) {
+        bfly(u[e3][0], u[e3][1], u[e3][2], u[e3][3], tw.s5[e3][0][0], tw.s5[e3][0][1], tw.s5[e3][1][0],
+             tw.s5[e3][1][1], tw.s5[e3][2][0], tw.s5[e3][2][1]);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; e4++) out[lane + 64 * e3 + 256 * e4] = u[e3][e4];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_fft_q15(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables t)
+{
+    __shared__ uint32_t buf[kXchgWords];
+    const int lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        fft_full_wave(in + (size_t)i * kNfft, out + (size_t)i * kNfft, buf, lane, t);
+        wave_sync();
+    }
+}
+
+void launch_fft_q15(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_fft_q15, dim3(n < 4096 ? n : 4096), dim3(64), 0, s, in, out, n, t);
+}
+
+// fft() of MFCC.C:27-62 on its own: zero-extend len samples, FFT, magnitudes of bins 0..511.
+__global__ void __launch_bounds__(64) k_fft_mag(const int16_t *frames, uint32_t len, uint32_t *mag, uint32_t *raw_hi,
+                                                uint32_t n, const DevTables t)
+{
+    __shared__ uint32_t buf[kXchgWords];
+    __shared__ uint32_t fin[kNfft], fout[kNfft];
+    const int lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        for (int k = lane; k < kNfft; k += 64) fin[k] = (k < (int)len) ? (uint32_t)(uint16_t)frames[(size_t)i * len + k] : 0u;
+        wave_sync();
+        fft_full_wave(fin, fout, buf, lane, t);
+        wave_sync();
+        for (int k = lane; k < kBins; k += 64) {
+            const int re = sext_lo(fout[k]), im = sext_hi(fout[k]);
+            const int r = re * re + im * im;
+            mag[(size_t)i * kBins + k] = (uint32_t)(sqrtf((float)r) * 10.0f);
+            if (raw_hi) raw_hi[(size_t)i * kBins + k] = fout[kBins + k];
+        }
+        wave_sync();
+    }
+}
+
+void launch_fft_mag(const int16_t *frames, uint32_t len, uint32_t *mag, uint32_t *raw_hi, uint32_t n, const DevTables &t,
+                    hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_fft_mag, dim3(n < 4096 ? n : 4096), dim3(64), 0, s, frames, len, mag, raw_hi, n, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_vad: one wave per capture buffer
+// ------------------------------------------------------------------------------------------------
+constexpr int kVadWaves = 4;
+
+__device__ __forceinline__ uint32_t absdiff(uint32_t v, uint32_t mid) { return v > mid ? v - mid : mid - v; }
+
+__global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * kVadWaves + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const uint4 *row = (const uint4 *)(a.pcm + (uint64_t)b * a.pcm_stride);
+    const uint32_t S = a.buf_len;
+
+    // ---- noise_atap (VAD.C:22-71) over the first noise_len samples --------------------------
+    uint32_t mid, n_thl, z_thl, s_thl;
+    if (a.atap_in) {
+        mid = a.atap_in[b].mid_val;
+        n_thl = a.atap_in[b].n_thl;
+        z_thl = a.atap_in[b].z_thl;
+        s_thl = a.atap_in[b].s_thl;
+    } else {
+        const uint32_t nvec = a.noise_len / 8;
+        uint32_t part = 0;
+        for (uint32_t v = lane; v < nvec; v += 64) {
+            const uint4 q = row[v];
+            part += (q.x & 0xFFFF) + (q.x >> 16) + (q.y & 0xFFFF) + (q.y >> 16) + (q.z & 0xFFFF) + (q.z >> 16) +
+                    (q.w & 0xFFFF) + (q.w >> 16);
+        }
+        mid = wave_sum(part) / a.noise_len;  // VAD.C:41-45
+        const uint32_t nblk = a.noise_len / a.atap_frm, vpb = a.atap_frm / 8;
+        uint32_t max_sum = 0, abs_part = 0;
+        for (uint32_t blk = 0; blk < nblk; blk++) {  // VAD.C:48-63
+            uint32_t nmax = 0;
+            for (uint32_t v = lane; v < vpb; v += 64) {
+                const uint4 q = row[blk * vpb + v];
+                const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const uint32_t ad = absdiff((wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF, mid);
+                    nmax = ad > nmax ? ad : nmax;
+                    abs_part += ad;
+                }
+            }
+            max_sum += wave_max(nmax);
+        }
+        uint32_t abs_sum = wave_sum(abs_part);
+        abs_sum /= (a.noise_len / (uint32_t)kFrameLen);  // VAD.C:65 (divides by n_len/frame_len)
+        max_sum /= nblk;                                 // VAD.C:66
+        n_thl = max_sum & 0xFFFF;                        // u16 field, n_thl_ratio = 1
+        s_thl = abs_sum * 11 / 10;                       // s_thl_ratio
+        z_thl = (uint32_t)kFrameLen * 2 / 160 / 1;       // VAD.C:70
+    }
+    const uint32_t a_thl = mid + n_thl, b_thl = mid - n_thl;  // VAD.C:112-113 (u32, may wrap)
+
+    // ---- per-frame short-time magnitude and band-crossing count (VAD.C:121-157) ----------------
+    // Frames start every 80 samples, so both quantities are assembled from per-80-sample block
+    // summaries.  Class of a sample: 2 above the band, 1 below, 0 inside.  last_sig is never
+    // reset (VAD.C:99): on entry to frame f it is the class of the last out-of-band sample at
+    // position <= 80f+78, because the previous frame already scanned up to there.
+    const uint32_t F = (S > (uint32_t)kFrameLen) ? (S - kFrameLen + kHop - 1) / kHop : 0;  // frames, VAD.C:121
+    uint32_t cur = 0, front = 0, back = 0, vcon = 0;  // VAD.C:100-102,109
+    // segment bounds go straight to the record as they are found (rare events, lane 0 only);
+    // segment 0 is also kept in registers for the frame count below
+    int seg0_start = -1, seg0_end = -1;
+    sr_vad_rec *rec_out = a.vad + b;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * SR_MAX_SEG; i++) rec_out->seg[i] = -1;
+    }
+    uint32_t carry = 0;  // class of the last out-of-band sample before the current round's first block
+    bool done = false;
+    const uint32_t v_durmin = 8, s_durmax = 11;  // VAD.C:72-75 at 20 ms / 10 ms framing
+
+    for (uint32_t jb = 0; jb < F && !done; jb += 63) {
+        const uint32_t j = jb + lane;  // block index; frame f = j uses blocks j and j+1
+        uint32_t A = 0, internal = 0, last = 0, cf = 0, c78 = 0;
+        int pfo = -1;
+        if (j <= F) {
+#pragma unroll
+            for (int t = 0; t < kHop / 8; t++) {
+                const uint4 q = row[(uint64_t)j * (kHop / 8) + t];
+                const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int off = t * 8 + s;
+                    const uint32_t x = (wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF;
+                    A += absdiff(x, mid);
+                    const uint32_t c = (x >= a_thl) ? 2u : (x < b_thl ? 1u : 0u);
+                    if (off == kHop - 1) c78 = last;
+                    const bool nz = c != 0;
+                    internal += (nz && last != 0 && last != c) ? 1u : 0u;
+                    const bool first = nz && last == 0;
+                    cf = first ? c : cf;
+                    pfo = first ? off : pfo;
+                    last = nz ? c : last;
+                }
+            }
+        }
+        const uint32_t c80 = last;
+        // R(j) = class of the last out-of-band sample in blocks <= j
+        uint32_t R = c80;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(R, d, 64);
+            if (lane >= d) R = R ? R : o;
+        }
+        R = R ? R : carry;
+        uint32_t Rprev = __shfl_up(R, 1, 64);
+        if (lane == 0) Rprev = carry;
+        carry = __shfl(R, 62, 64);
+        const uint32_t ff = (cf != 0 && Rprev != 0 && Rprev != cf) ? 1u : 0u;  // flip at the block's first out-of-band sample
+        const uint32_t fl = internal + ff;
+        const uint32_t fl_next = __shfl_down(fl, 1, 64), A_next = __shfl_down(A, 1, 64);
+        uint32_t Z = internal + fl_next;
+        if (pfo < 0 || pfo == kHop - 1)
+            Z += ff;  // entry state = history before the frame: natural count
+        else if (pfo > 0 && j > 0)
+            Z += (c78 != cf) ? 1u : 0u;  // entry state comes from inside the frame (positions <= 78);
+                                         // frame 0 starts with last_sig = 0 (VAD.C:99)
+        const uint32_t frm_sum = A + A_next;
+        const bool loud = (lane < 63) && (j < F) && (frm_sum > s_thl || Z > z_thl);  // VAD.C:164
+        const uint64_t mask = __ballot(loud);
+        if (a.dbg_masks && lane == 0) a.dbg_masks[(uint64_t)b * 16 + (jb / 63 < 16 ? jb / 63 : 15)] = mask;
+        const uint32_t nfr = (F - jb < 63u) ? F - jb : 63u;
+
+        // ---- endpoint state machine (VAD.C:164-216), wave-uniform ------------------------------
+        for (uint32_t t = 0; t < nfr; t++) {
+            const int i = (int)((jb + t) * kHop);
+            if ((mask >> t) & 1) {
+                if (cur == 0) {
+                    cur = 1;
+                    front = 1;
+                } else if (cur == 1) {
+                    front++;
+                    if (front >= v_durmin) {
+                        cur = 2;
+                        const int st = i - (int)((v_durmin - 1) * kHop);
+                        if (vcon == 0) seg0_start = st;
+                        if (lane == 0) rec_out->seg[2 * vcon] = st;
+                        front = 0;
+                    }
+                } else if (cur == 3) {
+                    back = 0;
+                    cur = 2;
+                }
+            } else {
+                if (cur == 2) {
+                    cur = 3;
+                    back = 1;
+                } else if (cur == 3) {
+                    back++;
+                    if (back >= s_durmax) {
+                        cur = 0;
+                        const int en = i - (int)(s_durmax * kHop) + kFrameLen;
+                        if (vcon == 0) seg0_end = en;
+                        if (lane == 0) rec_out->seg[2 * vcon + 1] = en;
+                        vcon++;
+                        if (vcon == a.max_seg) {
+                            done = true;
+                            break;
+                        }
+                        back = 0;
+                    }
+                } else if (cur == 1) {
+                    front = 0;
+                    cur = 0;
+                }
+            }
+        }
+    }
+
+    if (lane == 0) {
+        sr_atap at;
+        at.mid_val = mid;
+        at.n_thl = (uint16_t)n_thl;
+        at.z_thl = (uint16_t)z_thl;
+        at.s_thl = s_thl;
+        rec_out->atap = at;
+        uint32_t frm = 0, status;
+        if (seg0_end < 0) {
+            status = SR_ST_VAD_FAIL;
+        } else if (seg0_start < 1) {
+            status = SR_ST_SEG_OOB;
+        } else {
+            // MFCC.C:102: u32 arithmetic, result truncated to u16
+            const uint32_t n = ((((uint32_t)(seg0_end - seg0_start) - kFrameLen) / kHop) + 1) & 0xFFFF;
+            if (n > a.max_frames) {
+                status = SR_ST_MFCC_FAIL;
+            } else {
+                status = SR_ST_OK;
+                frm = n;
+            }
+        }
+        rec_out->frm_num = frm;
+        rec_out->status = status;
+        rec_out->_pad = 0;
+    }
+}
+
+void launch_vad(const VadArgs &a, hipStream_t s)
+{
+    if (!a.B) return;
+    hipLaunchKernelGGL(k_vad, dim3((a.B + kVadWaves - 1) / kVadWaves), dim3(64 * kVadWaves), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dtw: one lane per (utterance, template) pair, greedy local walk of DTW.C:120-192
+// ------------------------------------------------------------------------------------------------
+struct Frame12 {
+    uint32_t w[6];
+};
+__device__ __forceinline__ Frame12 load_frame(const int16_t *p)
+{
+    const uint2 *q = (const uint2 *)p;  // rows are 24 bytes, 8-byte aligned
+    const uint2 a = q[0], b = q[1], c = q[2];
+    Frame12 f;
+    f.w[0] = a.x;
+    f.w[1] = a.y;
+    f.w[2] = b.x;
+    f.w[3] = b.y;
+    f.w[4] = c.x;
+    f.w[5] = c.y;
+    return f;
+}
+__device__ __forceinline__ uint32_t norm2(const Frame12 &f)
+{
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc = sdot2(f.w[i], f.w[i], acc);
+    return (uint32_t)acc;
+}
+// get_dis (DTW.C:45-62): sum (a-b)^2 in u32 wrap = |a|^2 + |b|^2 - 2 a.b in the same ring
+__device__ __forceinline__ uint32_t get_dis_dev(const Frame12 &fa, uint32_t na, const Frame12 &fb, uint32_t nb)
+{
+    int dot = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dot = sdot2(fa.w[i], fb.w[i], dot);
+    const uint32_t d = na + nb - 2u * (uint32_t)dot;
+    return (uint32_t)sqrtf((float)d);
+}
+// dtw_limit (DTW.C:76-109); returns true when (x, y) is OUTSIDE the relaxed parallelogram
+__device__ __forceinline__ bool dtw_out(int x, int y, int X1, int X2, int in_n, int mdl_n)
+{
+    const bool o1 = (x < X1) ? (y >= 2 * x + 2) : (2 * y + in_n - 2 * mdl_n >= x + 4);
+    const bool o2 = (x < X2) ? (2 * y + 2 <= x) : (y + 4 <= 2 * x + mdl_n - 2 * in_n);
+    return o1 || o2;
+}
+
+__device__ uint32_t dtw_pair(const int16_t *in, uint32_t in_n, uint32_t in_rows, const int16_t *mdl, uint32_t mdl_n,
+                             uint32_t mdl_rows)
+{
+    if (in_n > mdl_n * 2 || 2 * in_n < mdl_n) return SR_DIS_ERR;  // DTW.C:133-137
+    const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142 (u16 statics)
+    const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
+    uint32_t px = 0, py = 0;  // 0-based rows under the in / mdl pointers (x = px+1, y = py+1)
+    Frame12 ci = load_frame(in), cm = load_frame(mdl);
+    uint32_t nci = norm2(ci), ncm = norm2(cm);
+    uint32_t dis = get_dis_dev(ci, nci, cm, ncm);
+    uint32_t step = 1;
+    do {
+        // rows px+1 / py+1 are read even when they lie past the sequence end (do-while, DTW.C:150-154);
+        // clamped to the allocated rows so the access stays inside the buffer
+        const uint32_t rx = (px + 1 < in_rows) ? px + 1 : in_rows - 1, ry = (py + 1 < mdl_rows) ? py + 1 : mdl_rows - 1;
+        const Frame12 ni = load_frame(in + (size_t)rx * kCoef), nm = load_frame(mdl + (size_t)ry * kCoef);
+        const uint32_t nni = norm2(ni), nnm = norm2(nm);
+        const int x = (int)px + 1, y = (int)py + 1;
+        const uint32_t up = dtw_out(x, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_dev(nm, nnm, ci, nci);
+        const uint32_t right = dtw_out(x + 1, y, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_dev(cm, ncm, ni, nni);
+        const uint32_t diag =
+            dtw_out(x + 1, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_dev(nm, nnm, ni, nni);
+        uint32_t mn = diag;  // DTW.C:156-164
+        if (mn > right) mn = right;
+        if (mn > up) mn = up;
+        dis += mn;
+        const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
+        const bool adv_x = mv_diag || !mv_up, adv_y = mv_diag || mv_up;
+        if (adv_x) {
+            ci = ni;
+            nci = nni;
+            px++;
+        }
+        if (adv_y) {
+            cm = nm;
+            ncm = nnm;
+            py++;
+        }
+        step = (step + 1) & 0xFFFF;  // u16 step
+    } while (px + 1 < in_n && py + 1 < mdl_n);  // DTW.C:188
+    return dis / step;
+}
+
+__global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
+{
+    const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= (uint64_t)a.B * a.K) return;
+    const uint32_t b = (uint32_t)(pid / a.K), k = (uint32_t)(pid - (uint64_t)b * a.K);
+    uint32_t in_n, ok;
+    if (a.in_frames) {
+        in_n = a.in_frames[b];
+        ok = in_n != 0;
+    } else {
+        in_n = a.vad[b].frm_num;
+        ok = a.vad[b].status == SR_ST_OK && in_n != 0;
+    }
+    uint32_t d = SR_DIS_ERR;
+    if (ok && a.tpl_valid[k])  // main.c:283
+        d = dtw_pair(a.mfcc + (size_t)b * a.max_frames * kCoef, in_n, a.max_frames, a.tpl + (size_t)k * a.tpl_stride,
+                     a.tpl_frames[k], a.tpl_rows);
+    a.scores[pid] = d;
+}
+
+void launch_dtw(const DtwArgs &a, hipStream_t s)
+{
+    const uint64_t n = (uint64_t)a.B * a.K;
+    if (!n) return;
+    hipLaunchKernelGGL(k_dtw, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
+}
+
+// argmin with strict '<' in slot order (main.c:276-291): first minimum wins; all dis_err -> slot 0
+__global__ void __launch_bounds__(256) k_argmin(const DtwArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const uint32_t *sc = a.scores + (size_t)b * a.K;
+    uint32_t best = SR_DIS_ERR, idx = 0xFFFFFFFFu;
+    for (uint32_t k = lane; k < a.K; k += 64) {
+        const uint32_t d = sc[k];
+        if (d < best) {
+            best = d;
+            idx = k;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t ob = __shfl_xor(best, d, 64), oi = __shfl_xor(idx, d, 64);
+        if (ob < best || (ob == best && oi < idx)) {
+            best = ob;
+            idx = oi;
+        }
+    }
+    if (lane == 0) {
+        sr_result r;
+        r.best_tpl = (best == SR_DIS_ERR) ? 0u : idx;
+        r.min_dis = best;
+        if (a.in_frames) {
+            r.frm_num = a.in_frames[b];
+            r.status = SR_ST_OK;
+        } else {
+            r.frm_num = a.vad[b].frm_num;
+            r.status = a.vad[b].status;
+        }
+        a.results[b] = r;
+    }
+}
+
+void launch_argmin(const DtwArgs &a, hipStream_t s)
+{
+    if (!a.B) return;
+    hipLaunchKernelGGL(k_argmin, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers of DTW.C exposed by the reference-compatible symbols
+// ------------------------------------------------------------------------------------------------
+__global__ void k_get_dis(const int16_t *pa, const int16_t *pb, uint32_t *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Frame12 fa = load_frame(pa + (size_t)i * kCoef), fb = load_frame(pb + (size_t)i * kCoef);
+    out[i] = get_dis_dev(fa, norm2(fa), fb, norm2(fb));
+}
+void launch_get_dis(const int16_t *pa, const int16_t *pb, uint32_t *out, uint32_t n, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_get_dis, dim3((n + 63) / 64), dim3(64), 0, s, pa, pb, out, n);
+}
+
+__global__ void k_dtw_limit(const uint16_t *xy, uint8_t *out, uint32_t n, int X1, int X2, int in_n, int mdl_n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = dtw_out((int)xy[2 * i], (int)xy[2 * i + 1], X1, X2, in_n, mdl_n) ? 1 : 0;
+}
+void launch_dtw_limit(const uint16_t *xy, uint8_t *out, uint32_t n, int X1, int X2, int in_n, int mdl_n, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_dtw_limit, dim3((n + 63) / 64), dim3(64), 0, s, xy, out, n, X1, X2, in_n, mdl_n);
+}
+
+}  // namespace sr

@@ -1,0 +1,38 @@
+// Constant tables of the recognition front end, generated on the host at sr_create() and
+// uploaded once to HBM.  Reference: Src/Speech_Recog/MFCC_Arg.h:6-44 (pasted Matlab output),
+// generator formulas Matlab/matlab仿真/speech_recog.m:217-310 and teat.m:19-27; FFT coefficient
+// table Src/BSP/cr4_fft_1024_stm32.s:285-629.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace sr {
+
+constexpr int kFrameLen = 160;  // VAD.H:7 at fs = 8000
+constexpr int kHop = 80;        // frame_len - frame_mov, VAD.H:8
+constexpr int kNfft = 1024;     // MFCC.H:8
+constexpr int kBins = 512;      // frq_max, MFCC.H:9
+constexpr int kMel = 24;        // tri_num, MFCC.H:12
+constexpr int kCoef = 12;       // mfcc_num, MFCC.H:13
+constexpr int kTwiddles = 1020; // 3 per butterfly, passes N = 16, 64, 256, 1024
+constexpr int kLogMax = 2218;   // floor(100*ln(2^32-1))
+
+struct HostTables {
+    std::vector<uint16_t> hamm;      // [160]
+    std::vector<uint16_t> tri_cen;   // [24]
+    std::vector<uint16_t> tri_even;  // [512]
+    std::vector<uint16_t> tri_odd;   // [512]
+    std::vector<int8_t> dct;         // [12*24]
+    // Per twiddle K = Kc + i*Ks (Q14; Kc = Kr' + Ki of the ST table) two packed words so that
+    // Y*conj(K) is two 16-bit dot products of the packed sample (re lo, im hi):
+    //   tw_a = (Kc, Ks)   -> re' = Yr*Kc + Yi*Ks
+    //   tw_b = (-Ks, Kc)  -> im' = Yi*Kc - Yr*Ks
+    std::vector<uint32_t> tw_a, tw_b;  // [1020]
+    std::vector<int16_t> tw_kr, tw_ki; // raw (Kr', Ki) as in the .s table, for tests
+    // log_thr[m] = smallest n with (u32)(log((double)n)*100) >= m, m = 0..2218; [2219] = sentinel.
+    std::vector<uint32_t> log_thr;
+};
+
+void build_tables(HostTables &t);
+
+}  // namespace sr

@@ -1,0 +1,226 @@
+"""Host-side mirror of include/sr_engine.h (ctypes over the C ABI of libsr_engine.so).
+
+The shared library holds the hand-written gfx950 kernels; this module only moves pointers.
+PyTorch is used for device memory and streams (plumbing).  There is no fallback: if the library is
+missing, or no MI355X is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsr_engine.so")
+
+DIS_ERR = 0xFFFFFFFF
+ST_OK, ST_VAD_FAIL, ST_MFCC_FAIL, ST_SEG_OOB = 0, 1, 2, 3
+N_COEF = 12
+
+RESULT_DTYPE = np.dtype([("best_tpl", "<u4"), ("min_dis", "<u4"), ("frm_num", "<u4"), ("status", "<u4")])
+VAD_DTYPE = np.dtype([("mid_val", "<u4"), ("n_thl", "<u2"), ("z_thl", "<u2"), ("s_thl", "<u4"),
+                      ("seg", "<i4", (6,)), ("frm_num", "<u4"), ("status", "<u4"), ("_pad", "<u4")])
+assert RESULT_DTYPE.itemsize == 16 and VAD_DTYPE.itemsize == 48
+
+
+class Config(C.Structure):
+    _fields_ = [("fs", C.c_uint32), ("frame_time_ms", C.c_uint32), ("frame_mov_ms", C.c_uint32),
+                ("nfft", C.c_uint32), ("n_mel", C.c_uint32), ("n_coef", C.c_uint32), ("max_frames", C.c_uint32),
+                ("noise_len_ms", C.c_uint32), ("max_seg", C.c_uint32), ("device", C.c_int32)]
+
+
+class SrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsr_engine.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SrError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.sr_last_error.restype = C.c_char_p
+        L.sr_num_templates.restype = C.c_uint32
+        L.sr_num_templates.argtypes = [C.c_void_p]
+        L.sr_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _vp(x):
+    """void* of a numpy array, a torch tensor, an int address or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.data_ptr())
+
+
+class Engine:
+    """One sr_engine handle.  Defaults are the firmware's constants except where overridden."""
+
+    def __init__(self, max_frames=119, device=-1, **kw):
+        self.L = load_library()
+        cfg = Config()
+        self.L.sr_default_config(C.byref(cfg))
+        cfg.max_frames = max_frames
+        cfg.device = device
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        self._check(self.L.sr_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.max_frames = max_frames
+        self.noise_len = (cfg.fs // 1000) * cfg.noise_len_ms
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SrError(f"sr_engine error {rc}: {self.L.sr_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- template store ---------------------------------------------------------------------------
+    @property
+    def n_templates(self):
+        return self.L.sr_num_templates(self.h)
+
+    def set_templates_dense(self, mfcc, frames, valid=None):
+        """mfcc int16 [K, rows, 12]; frames uint32 [K]; valid uint8 [K] or None (all valid)."""
+        mfcc = np.ascontiguousarray(mfcc, dtype=np.int16)
+        frames = np.ascontiguousarray(frames, dtype=np.uint32)
+        if valid is not None:
+            valid = np.ascontiguousarray(valid, dtype=np.uint8)
+        K = mfcc.shape[0]
+        self._check(self.L.sr_set_templates_dense(self.h, _vp(mfcc), _vp(frames), _vp(valid), C.c_uint32(K),
+                                                  C.c_uint32(mfcc.shape[1] * mfcc.shape[2])))
+
+    def set_templates_store(self, store, stride=4096):
+        """Firmware flash image: v_ftr_tag slots at `stride` bytes (Flash.H:11-20)."""
+        store = np.ascontiguousarray(store, dtype=np.uint8)
+        self._check(self.L.sr_set_templates(self.h, _vp(store), C.c_uint32(len(store) // stride), C.c_uint32(stride)))
+
+    # ---- host-buffer API --------------------------------------------------------------------------
+    def recognize(self, pcm, want_scores=True, want_mfcc=True, want_vad=True, buf_len=None):
+        """pcm uint16 [B, S] on the host.  Returns dict(results, scores, mfcc, vad) of numpy arrays."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        B, S = pcm.shape
+        buf_len = S if buf_len is None else buf_len
+        K = self.n_templates
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        sc = np.zeros((B, K), dtype=np.uint32) if want_scores else None
+        mf = np.zeros((B, self.max_frames, N_COEF), dtype=np.int16) if want_mfcc else None
+        vd = np.zeros(B, dtype=VAD_DTYPE) if want_vad else None
+        self._check(self.L.sr_recognize_batch(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(buf_len), C.c_uint32(B),
+                                              _vp(res), _vp(sc), _vp(mf), _vp(vd)))
+        return dict(results=res, scores=sc, mfcc=mf, vad=vd)
+
+    def vad(self, pcm, buf_len=None):
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        B, S = pcm.shape
+        vd = np.zeros(B, dtype=VAD_DTYPE)
+        self._check(self.L.sr_vad_batch(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S if buf_len is None else buf_len),
+                                        C.c_uint32(B), _vp(vd)))
+        return vd
+
+    def mfcc(self, pcm, start, end, mid):
+        """get_mfcc of segment [start[b], end[b]) of row b with mid value mid[b]."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        B, S = pcm.shape
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32)
+        mid = np.ascontiguousarray(mid, dtype=np.uint32)
+        out = np.zeros((B, self.max_frames, N_COEF), dtype=np.int16)
+        n = np.zeros(B, dtype=np.uint32)
+        self._check(self.L.sr_mfcc_batch(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B), _vp(start),
+                                         _vp(end), _vp(mid), _vp(out), _vp(n)))
+        return n, out
+
+    def dtw(self, in_mfcc, in_frames):
+        """in_mfcc int16 [B, max_frames, 12] against the template store -> (scores [B,K], results [B])."""
+        in_mfcc = np.ascontiguousarray(in_mfcc, dtype=np.int16)
+        assert in_mfcc.shape[1:] == (self.max_frames, N_COEF)
+        in_frames = np.ascontiguousarray(in_frames, dtype=np.uint32)
+        B = in_mfcc.shape[0]
+        sc = np.zeros((B, self.n_templates), dtype=np.uint32)
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        self._check(self.L.sr_dtw_batch(self.h, _vp(in_mfcc), _vp(in_frames), C.c_uint32(B), _vp(sc), _vp(res)))
+        return sc, res
+
+    def fft_q15(self, words):
+        """cr4_fft_1024_stm32 on uint32 [n, 1024] packed complex arrays."""
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        out = np.zeros_like(words)
+        self._check(self.L.sr_fft_q15_batch(self.h, _vp(words), _vp(out), C.c_uint32(words.shape[0])))
+        return out
+
+    # ---- device-resident API (torch tensors as HBM handles) ---------------------------------------------
+    def alloc_outputs(self, B, device, scores=True, mfcc=True, vad=True):
+        import torch
+        K = self.n_templates
+        o = dict(results=torch.empty(B, 4, dtype=torch.int32, device=device))
+        o["scores"] = torch.empty(B, K, dtype=torch.int32, device=device) if scores else None
+        o["mfcc"] = torch.empty(B, self.max_frames, N_COEF, dtype=torch.int16, device=device) if mfcc else None
+        o["vad"] = torch.empty(B, 12, dtype=torch.int32, device=device) if vad else None
+        return o
+
+    def recognize_dev(self, pcm, out, buf_len=None, stream=None):
+        """pcm: torch int16 [B, S] in HBM holding the u16 ADC codes; out: alloc_outputs().  Asynchronous."""
+        import torch
+        assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous()
+        B, S = pcm.shape
+        if stream is None:
+            stream = torch.cuda.current_stream(pcm.device).cuda_stream
+        self._check(self.L.sr_recognize_batch_dev(
+            self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S if buf_len is None else buf_len), C.c_uint32(B),
+            _vp(out["results"]), _vp(out["scores"]), _vp(out["mfcc"]), _vp(out["vad"]), C.c_void_p(stream)))
+        return out
+
+    def features_dev(self, pcm, buf_len=None, stream=None):
+        """VAD + MFCC only (template creation = the same front end, main.c:121-138).
+        Returns (vad [B,12] int32, mfcc [B,max_frames,12] int16) device tensors."""
+        import torch
+        assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous()
+        B, S = pcm.shape
+        if stream is None:
+            stream = torch.cuda.current_stream(pcm.device).cuda_stream
+        vad = torch.empty(B, 12, dtype=torch.int32, device=pcm.device)
+        mfcc = torch.empty(B, self.max_frames, N_COEF, dtype=torch.int16, device=pcm.device)
+        self._check(self.L.sr_vad_batch_dev(self.h, _vp(pcm), C.c_uint64(S),
+                                            C.c_uint32(S if buf_len is None else buf_len), C.c_uint32(B), _vp(vad),
+                                            C.c_void_p(stream)))
+        self._check(self.L.sr_mfcc_batch_dev(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(B), _vp(vad), _vp(mfcc),
+                                             C.c_void_p(stream)))
+        return vad, mfcc
+
+    def set_profiling(self, on=True):
+        self._check(self.L.sr_set_profiling(self.h, C.c_int(1 if on else 0)))
+
+    def stage_ms(self):
+        ms = (C.c_float * 5)()
+        self._check(self.L.sr_get_stage_ms(self.h, ms))
+        return dict(vad=ms[0], mfcc=ms[1], dtw=ms[2], argmin=ms[3], total=ms[4])
+
+
+def results_from_torch(t):
+    """[B,4] int32 device tensor -> numpy structured sr_result array."""
+    return t.cpu().numpy().view(np.uint32).reshape(-1, 4).copy().view(RESULT_DTYPE).reshape(-1)
+
+
+def vad_from_torch(t):
+    return t.cpu().numpy().view(np.uint8).reshape(-1, 48).copy().view(VAD_DTYPE).reshape(-1)

@@ -1,0 +1,263 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle and the
+committed golden fixtures (which come from the reference's own objects).  Bit-exact everywhere:
+the whole path is integer except sqrtf / log, which are reproduced exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as ol
+from stm32_speech_recognition_amd import synth
+from test_oracle import store_to_templates
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+@pytest.fixture(scope="module")
+def eng119():
+    from stm32_speech_recognition_amd import Engine
+    e = Engine(max_frames=119, device=0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return ol.Oracle(max_frames=119)
+
+
+def test_library_loaded_is_in_tree():
+    from stm32_speech_recognition_amd import engine
+    engine.load_library()
+    assert os.path.exists(engine.LIB_PATH)
+    assert "libsr_engine.so" in open("/proc/self/maps").read()
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+def test_fft_q15_matches_golden(eng119, golden):
+    """generic complex FFT (cr4_fft_1024_stm32 symbol) incl. full-scale inputs"""
+    got = eng119.fft_q15(golden["fft_in"])
+    assert np.array_equal(got, golden["fft_out"])
+
+
+def test_vad_matches_golden(eng119, golden):
+    vd = eng119.vad(golden["pcm"])
+    assert np.array_equal(np.stack([vd["mid_val"], vd["n_thl"], vd["z_thl"], vd["s_thl"]], 1), golden["atap"])
+    assert np.array_equal(vd["seg"], golden["seg"])
+    assert np.array_equal(vd["frm_num"], golden["frm_num"])
+
+
+def test_recognize_matches_golden(eng119, golden):
+    eng119.set_templates_store(golden["store"])
+    out = eng119.recognize(golden["pcm"])
+    n = golden["frm_num"]
+    for b in range(len(n)):
+        assert np.array_equal(out["mfcc"][b, :n[b]], golden["mfcc"][b, :n[b]]), b
+        assert not out["mfcc"][b, n[b]:].any()
+    assert np.array_equal(out["scores"], golden["recg_scores"])
+    assert np.array_equal(out["results"]["best_tpl"], golden["recg_best"])
+    assert np.array_equal(out["results"]["min_dis"], golden["recg_dis"])
+    assert np.array_equal(out["results"]["status"], golden["recg_status"])
+
+
+def test_direct_mfcc_edge_cases_match_golden(eng119, golden):
+    """log(0) frames, s16 wrap after windowing, u32 wrap in the filterbank, full-range u16 codes"""
+    dp, dmid, dm = golden["direct_pcm"], golden["direct_mid"], golden["direct_mfcc"]
+    D, nfd = dm.shape[0], dm.shape[1]
+    n, m = eng119.mfcc(dp, np.ones(D, np.int32), np.full(D, 1 + 160 + 80 * (nfd - 1), np.int32), dmid)
+    assert (n == nfd).all()
+    assert np.array_equal(m[:, :nfd], dm)
+
+
+def test_dtw_matches_golden(golden):
+    """400 random pairs incl. every length gate and full-scale coefficients, one template per engine call"""
+    from stm32_speech_recognition_amd import Engine
+    ln, da, db, dd = golden["dtw_len"], golden["dtw_a"], golden["dtw_b"], golden["dtw_dis"]
+    e = Engine(max_frames=119, device=0)
+    # all models as one store, all inputs as one batch: score[p, p] is the pair's distance
+    P = len(dd)
+    e.set_templates_dense(np.concatenate([db, np.zeros((P, 1, 12), np.int16)], 1), ln[:, 1])
+    sc, _ = e.dtw(da, ln[:, 0])
+    assert np.array_equal(np.diagonal(sc), dd)
+    e.close()
+
+
+# ----------------------------------------------------------------------------- oracle on fresh inputs
+def _oracle_templates(orc, bank, frames, seed, S):
+    K = len(frames)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(K) % bank[0].shape[0], frames, seed=seed, bank=bank, S=S))
+    tm = np.zeros((K, max(frames) + 1, 12), np.int16)
+    for k in range(K):
+        rc, a = orc.noise_atap(tp[k])
+        seg = orc.vad(tp[k], a)
+        n, m = orc.mfcc(tp[k], seg[0], seg[1], a)
+        assert n == frames[k]
+        tm[k, :n] = m
+    return tm, np.array(frames, np.uint32)
+
+
+@pytest.mark.parametrize("T,B,K", [(256, 256, 100), (119, 512, 10)])
+def test_full_path_matches_oracle(T, B, K):
+    """BASELINE configs 2/3 shapes at a batch the oracle finishes in seconds: MFCC s16 exact,
+    all K scores u32 exact, argmin exact."""
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch
+    rng = np.random.default_rng(T + B)
+    maxf = T + 64
+    orc = ol.Oracle(max_frames=maxf)
+    bank = synth.word_bank(10)
+    tfr = [int(v) for v in rng.integers(int(0.75 * T), int(1.25 * T), K)]
+    tfr[3] = max(2, T // 2 - 5)  # outside the 1/2..2x gate of DTW.C:133 -> dis_err
+    tm, tf = _oracle_templates(orc, bank, tfr, seed=7, S=synth.buf_len_for(max(tfr)))
+    valid = np.ones(K, np.uint8)
+    valid[5] = 0
+    S = synth.buf_len_for(T)
+    pcm_t = synth.make_utterances(rng.integers(0, 10, B), [T] * B, seed=99, bank=bank, S=S, device="cuda:0")
+    # a few rows with noisy quiet parts (segment length varies), one silent row (VAD fail)
+    noisy = synth.make_utterances(rng.integers(0, 10, 8), [T - 20] * 8, seed=5, bank=bank, S=S, quiet_sigma=8.0)
+    pcm_t[:8] = noisy.to("cuda:0")
+    pcm_t[8] = 2048
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf, valid)
+    out = eng.recognize_dev(pcm_t, eng.alloc_outputs(B, "cuda:0"))
+    torch.cuda.synchronize()
+    res = results_from_torch(out["results"])
+    vd = vad_from_torch(out["vad"])
+    tpl = orc.make_templates(tm, tf, valid)
+    ores, omf, osc = orc.recognize_batch(synth.as_u16_numpy(pcm_t), tpl, n_threads=8)
+    assert np.array_equal(vd["status"], ores["status"])
+    assert np.array_equal(out["mfcc"].cpu().numpy(), omf)
+    assert np.array_equal(out["scores"].cpu().numpy().view(np.uint32), osc)
+    for f in ("best_tpl", "min_dis", "frm_num", "status"):
+        assert np.array_equal(res[f], ores[f]), f
+    assert res["status"][8] == ol.ST_VAD_FAIL and res["min_dis"][8] == ol.DIS_ERR
+    assert (osc[:, 5] == ol.DIS_ERR).all() and (osc[9:, 3] == ol.DIS_ERR).all()
+    assert (res["frm_num"][9:] == T).all()
+    eng.close()
+
+
+def test_vad_stress_matches_oracle(eng119, oracle):
+    """random band-crossing activity: tight thresholds, DC steps, bursts -> exercises the block-summary
+    reconstruction of last_sig (VAD.C:99,131-157) against the sample-by-sample oracle"""
+    rng = np.random.default_rng(2024)
+    B, S = 96, 16000
+    pcm = np.zeros((B, S), np.uint16)
+    for b in range(B):
+        sig = rng.normal(0, rng.choice([2, 8, 30]), S)
+        nburst = rng.integers(0, 12)
+        for _ in range(nburst):
+            p = rng.integers(2400, S - 200)
+            ln = rng.integers(40, 3000)
+            amp = rng.choice([15, 40, 200, 1500])
+            f = rng.uniform(50, 3900)
+            seg = amp * np.sin(2 * np.pi * f * np.arange(ln) / 8000 + rng.uniform(0, 6.28))
+            sig[p:p + ln] += seg[:max(0, min(ln, S - p))]
+        if b % 7 == 0:
+            sig[rng.integers(2400, S):] += rng.choice([-60, 60])  # DC step: band re-entry from one side only
+        pcm[b] = np.clip(2048 + sig, 0, 4095).astype(np.uint16)
+    vd = eng119.vad(pcm)
+    nseg = 0
+    for b in range(B):
+        rc, a = oracle.noise_atap(pcm[b])
+        seg = oracle.vad(pcm[b], a)
+        assert (vd["mid_val"][b], vd["n_thl"][b], vd["z_thl"][b], vd["s_thl"][b]) == a.astuple(), b
+        assert np.array_equal(vd["seg"][b], seg), (b, vd["seg"][b], seg)
+        nseg += int((seg[1::2] >= 0).sum())
+    assert nseg > 40
+
+
+def test_dtw_stress_matches_oracle():
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(31)
+    maxf, K, B = 200, 37, 64
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(1, maxf, K).astype(np.uint32)
+    tm = rng.integers(-3000, 3000, (K, maxf + 1, 12)).astype(np.int16)
+    tm[::5] = rng.integers(-32768, 32767, (len(tm[::5]), maxf + 1, 12))
+    inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
+    im = rng.integers(-3000, 3000, (B, maxf, 12)).astype(np.int16)
+    im[::4] = rng.integers(-32768, 32767, (len(im[::4]), maxf, 12))
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf)
+    sc, res = eng.dtw(im, inf)
+    pad = np.zeros((1, 12), np.int16)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
+                    dtype=np.uint32)
+    assert np.array_equal(sc, want)
+    wb = np.array([int(np.argmin(w)) if w.min() != ol.DIS_ERR else 0 for w in want])
+    assert np.array_equal(res["best_tpl"], wb) and np.array_equal(res["min_dis"], want.min(1))
+    eng.close()
+
+
+def test_log_step_table_covers_all_steps(eng119, oracle):
+    """MFCC.C:168 on the device = table of step positions built from the host's libm; cross-check the
+    device path on filterbank-like magnitudes spanning 0 .. 2^32-1 via constant-spectrum frames is not
+    possible directly, so compare whole MFCCs on amplitude sweeps (every decade of pow_spct)."""
+    B, nf = 40, 12
+    S = 1 + 160 + 80 * (nf - 1) + 7
+    rng = np.random.default_rng(8)
+    pcm = np.zeros((B, S), np.uint16)
+    for b in range(B):
+        amp = 2.0 ** (b * 0.4 - 2)
+        pcm[b] = np.clip(2048 + rng.normal(0, 1, S) * amp, 0, 65535).astype(np.uint16)
+    mid = np.full(B, 2048, np.uint32)
+    n, m = eng119.mfcc(pcm, np.ones(B, np.int32), np.full(B, 1 + 160 + 80 * (nf - 1), np.int32), mid)
+    for b in range(B):
+        a = ol.Atap(2048, 10, 2, 1000)
+        n2, m2 = oracle.mfcc(pcm[b], 1, 1 + 160 + 80 * (nf - 1), a)
+        assert n[b] == n2 == nf and np.array_equal(m[b, :nf], m2), b
+
+
+# ----------------------------------------------------------------------------- reference-compatible symbols
+def test_compat_symbols_match_golden(golden, oracle):
+    from stm32_speech_recognition_amd import compat
+    pcm = golden["pcm"][0]
+    at = compat.atap_tag()
+    compat.noise_atap(pcm, compat.ATAP_LEN, at)
+    assert (at.mid_val, at.n_thl, at.z_thl, at.s_thl) == tuple(golden["atap"][0])
+    bad = compat.atap_tag(1, 2, 3, 4)
+    compat.noise_atap(pcm, 2399, bad)  # VAD.C:33-36: silent no-op
+    assert (bad.mid_val, bad.n_thl, bad.z_thl, bad.s_thl) == (1, 2, 3, 4)
+    segs = compat.VAD(pcm, compat.VCBUF_LEN, at)
+    want = golden["seg"][0]
+    for i in range(3):
+        assert segs[i] == (None if want[2 * i] < 0 else want[2 * i], None if want[2 * i + 1] < 0 else want[2 * i + 1])
+    for name in ("get_mfcc", "GetMfcc", "MFCC_Comp"):
+        ftr = compat.get_mfcc(pcm, segs[0][0], segs[0][1], at, name=name)
+        n = golden["frm_num"][0]
+        assert ftr.frm_num == n
+        assert np.array_equal(np.ctypeslib.as_array(ftr.mfcc_dat)[:n * 12].reshape(n, 12), golden["mfcc"][0, :n])
+    # fft(): magnitudes of a zero-padded real frame
+    frame = (golden["fft_in"][16, :160] & 0xFFFF).astype(np.uint16).view(np.int16)
+    fo = compat.fft(frame)
+    assert np.array_equal(fo[:512], oracle.fft_mag(frame))
+    assert np.array_equal(fo[512:], golden["fft_out"][16, 512:])
+    assert compat.fft(np.zeros(1025, np.int16)) is None  # MFCC.C:32-35
+    assert np.array_equal(compat.cr4_fft_1024_stm32(golden["fft_in"][3]), golden["fft_out"][3])
+    # dtw / get_dis / dtw_limit
+    ln, da, db, dd = golden["dtw_len"], golden["dtw_a"], golden["dtw_b"], golden["dtw_dis"]
+    for p in range(0, 40):
+        fa, fb = compat.make_ftr(da[p], int(ln[p, 0])), compat.make_ftr(db[p], int(ln[p, 1]))
+        assert compat.dtw(fa, fb) == dd[p], p
+    assert compat.get_dis(da[0, 0], db[0, 0]) == oracle.get_dis(da[0, 0], db[0, 0])
+    fa, fb = compat.make_ftr(da[1], 50), compat.make_ftr(db[1], 60)
+    compat.dtw(fa, fb)  # leaves X1 = 23, X2 = 26, in = 50, mdl = 60 behind (DTW.C:141-142)
+    assert compat.dtw_limit(1, 1) == 0 and compat.dtw_limit(1, 4) == 1 and compat.dtw_limit(10, 2) == 1
+    # spch_recg over the flash-layout store
+    compat.set_templates(golden["store"])
+    for b in range(4):
+        label, dis = compat.spch_recg(golden["pcm"][b])
+        assert dis == golden["recg_dis"][b]
+        idx = int(golden["recg_best"][b]) // 4
+        assert label is not None and label[:1] == str(idx).encode()
+    label, dis = compat.spch_recg(np.full(16000, 2048, np.uint16))
+    assert label is None and dis == compat.DIS_ERR  # main.c:261-266
