@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from stm32_speech_recognition_amd import Engine, synth  # noqa: E402
+from stm32_speech_recognition_amd import dist_util as du  # noqa: E402
 from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch  # noqa: E402
 
 T = 256            # frames per utterance (metric: "256-frame, 100 templates")
@@ -53,17 +54,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096, help="utterances timed on the host cores")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = du.env_rank()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        du.init_process_group("nccl", local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B = args.batch
@@ -85,7 +82,8 @@ def main():
     del tpcm, tvad, tmf
 
     # ---- this rank's shard of utterances, generated straight into HBM -------------------------------
-    words = torch.from_numpy(rng.integers(0, N_WORDS, (world, B)))[rank]
+    lo, hi = du.shard_bounds(world * B, world, rank)  # weak scaling: B utterances per rank
+    words = torch.from_numpy(rng.integers(0, N_WORDS, world * B))[lo:hi]
     pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev)
     out = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
     gathered = torch.empty(world * B, K, dtype=torch.int32, device=dev) if world > 1 else None
@@ -93,7 +91,7 @@ def main():
     def step():
         eng.recognize_dev(pcm, out)
         if world > 1:  # the path's one exchange step: all-gather of per-template scores over xGMI
-            dist.all_gather_into_tensor(gathered, out["scores"])
+            du.all_gather_scores(out["scores"], world, out=gathered)
 
     for _ in range(args.warmup):
         step()
@@ -114,10 +112,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = du.max_over_ranks(dt, dev, world)
     stage = eng.stage_ms()  # hipEvent timings of the timed steps, on the launch stream
     eng.set_profiling(False)
 

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing: one process per GPU, utterances sharded over ranks, templates replicated,
+ONE collective per step (all-gather of the per-template score matrix).  torch.distributed backend
+"nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (tests/test_sharding_gloo.py)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend, local_rank=0):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+
+
+def shard_bounds(n_total, world, rank):
+    """Contiguous utterance range [lo, hi) of `rank`; sizes differ by at most 1 (ragged totals allowed)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_scores(local_scores, world, out=None):
+    """local_scores: [B_local, K] (same B_local on every rank) -> [world*B_local, K], rank-major,
+    i.e. global utterance order when shards are contiguous.  One collective."""
+    if world == 1:
+        return local_scores
+    if out is None:
+        out = torch.empty((world * local_scores.shape[0],) + tuple(local_scores.shape[1:]), dtype=local_scores.dtype,
+                          device=local_scores.device)
+    dist.all_gather_into_tensor(out, local_scores.contiguous())
+    return out
+
+
+def max_over_ranks(value, device, world):
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def argmin_first(scores):
+    """Strict-< scan in slot order (main.c:285): first minimum wins, all dis_err -> slot 0.
+    scores: int32 tensor holding u32 bit patterns."""
+    u = scores.to(torch.int64) & 0xFFFFFFFF
+    mn, idx = torch.min(u, dim=1)
+    # torch.min returns an arbitrary index among equal minima on some backends: recompute the first
+    first = (u == mn.unsqueeze(1)).to(torch.int64).argmax(dim=1)
+    first = torch.where(mn == 0xFFFFFFFF, torch.zeros_like(first), first)
+    return first, mn

@@ -1,0 +1,74 @@
+"""world_size-2 CPU test (gloo) of the N>1 bookkeeping bench.py uses: contiguous utterance shards,
+one all-gather of the [B_local, K] score matrix, max-over-ranks timing, first-minimum argmin."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from stm32_speech_recognition_amd import dist_util as du
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_scores(lo, hi, K):
+    """deterministic u32 'DTW scores' of global utterances lo..hi-1, with ties and dis_err rows"""
+    g = np.arange(lo, hi, dtype=np.uint64)[:, None]
+    k = np.arange(K, dtype=np.uint64)[None, :]
+    s = ((g * 2654435761 + k * 40503) % 977).astype(np.uint32)
+    s[g[:, 0] % 7 == 3] = 0xFFFFFFFF          # utterances with no valid match
+    s[:, 5] = 0xFFFFFFFF                       # an erased template slot
+    return s
+
+
+def _worker(rank, world, port, B_total, K, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    du.init_process_group("gloo")
+    lo, hi = du.shard_bounds(B_total, world, rank)
+    local = torch.from_numpy(_fake_scores(lo, hi, K).view(np.int32))
+    gathered = du.all_gather_scores(local, world)
+    t = du.max_over_ranks(1.0 + rank, "cpu", world)
+    best, mn = du.argmin_first(gathered)
+    q.put((rank, lo, hi, gathered.numpy().view(np.uint32).copy(), t, best.numpy(), mn.numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 64, 65537):
+        for w in (1, 2, 3, 8):
+            b = [du.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_allgather_of_scores():
+    world, B_total, K = 2, 64, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B_total, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _fake_scores(0, B_total, K)
+    for rank, lo, hi, gathered, t, best, mn in outs:
+        assert (lo, hi) == (rank * 32, rank * 32 + 32)
+        assert np.array_equal(gathered, want)          # rank-major gather == global utterance order
+        assert t == 2.0                                # max over ranks of (1 + rank)
+        ref_mn = want.min(1)
+        ref_best = np.array([int(np.argmax(row == row.min())) if row.min() != 0xFFFFFFFF else 0 for row in want])
+        assert np.array_equal(mn, ref_mn.astype(np.int64)) and np.array_equal(best, ref_best)
