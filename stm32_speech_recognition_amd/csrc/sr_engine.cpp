@@ -3,6 +3,7 @@
 // in this library; every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -64,6 +65,8 @@ struct sr_engine {
     DevBuf<int16_t> tpl;
     DevBuf<uint32_t> tpl_frames;
     DevBuf<uint8_t> tpl_valid;
+    DevBuf<int16_t> tplT;          // [rows][K][12], templates ordered by length (k_dtw_lds)
+    DevBuf<uint32_t> tplN, tpl_frames_s, tpl_orig;
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
@@ -185,6 +188,10 @@ void sr_destroy(sr_engine *h)
     h->tpl.release();
     h->tpl_frames.release();
     h->tpl_valid.release();
+    h->tplT.release();
+    h->tplN.release();
+    h->tpl_frames_s.release();
+    h->tpl_orig.release();
     h->s_pcm.release();
     h->s_vad.release();
     h->s_mfcc.release();
@@ -211,6 +218,36 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     HIP_TRY(hipMemcpy(h->tpl.p, m.data(), m.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->tpl_frames.p, f.data(), K * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->tpl_valid.p, v.data(), K, hipMemcpyHostToDevice));
+    // length-sorted, row-interleaved copy + squared norms for the LDS-staged DTW kernel
+    {
+        std::vector<uint32_t> order(K);
+        for (uint32_t k = 0; k < K; k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const uint32_t fx = v[x] ? f[x] : 0xFFFFFFFFu, fy = v[y] ? f[y] : 0xFFFFFFFFu;
+            return fx < fy;
+        });
+        std::vector<int16_t> mt((size_t)rows * K * kCoef);
+        std::vector<uint32_t> nt((size_t)rows * K), fs(K);
+        for (uint32_t ks = 0; ks < K; ks++) {
+            const uint32_t k = order[ks];
+            fs[ks] = v[k] ? f[k] : 0u;
+            for (uint32_t r = 0; r < rows; r++) {
+                const int16_t *src = &m[((size_t)k * rows + r) * kCoef];
+                std::memcpy(&mt[((size_t)r * K + ks) * kCoef], src, kCoef * 2);
+                uint32_t nrm = 0;
+                for (int c = 0; c < kCoef; c++) nrm += (uint32_t)((int32_t)src[c] * (int32_t)src[c]);
+                nt[(size_t)r * K + ks] = nrm;
+            }
+        }
+        if ((rc = h->tplT.reserve(mt.size()))) return rc;
+        if ((rc = h->tplN.reserve(nt.size()))) return rc;
+        if ((rc = h->tpl_frames_s.reserve(K))) return rc;
+        if ((rc = h->tpl_orig.reserve(K))) return rc;
+        HIP_TRY(hipMemcpy(h->tplT.p, mt.data(), mt.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->tplN.p, nt.data(), nt.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->tpl_frames_s.p, fs.data(), K * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->tpl_orig.p, order.data(), K * 4, hipMemcpyHostToDevice));
+    }
     h->K = K;
     h->tpl_rows = rows;
     h->tpl_stride = rows * kCoef;
@@ -372,6 +409,10 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.tpl_rows = h->tpl_rows;
     a.scores = d_scores;
     a.results = d_results;
+    a.tplT = h->tplT.p;
+    a.tplN = h->tplN.p;
+    a.tpl_frames_s = h->tpl_frames_s.p;
+    a.tpl_orig = h->tpl_orig.p;
     return a;
 }
 

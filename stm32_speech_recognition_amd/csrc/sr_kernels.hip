@@ -803,11 +803,205 @@ __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
     a.scores[pid] = d;
 }
 
+// ---- k_dtw_lds: the production DTW kernel ---------------------------------------------------------
+// A workgroup owns U utterances whose MFCC rows (+ squared norms) are staged in LDS once and reused by
+// all K templates; lanes are the U*K pairs ordered (template-sorted-by-length major, utterance minor),
+// so the lanes of a wave walk sequences of nearly equal length (little trip-count divergence) and
+// touch at most ceil(64/U) templates.  Templates live in HBM/L2 in an interleaved layout
+// tplT[row][ks][12] (ks = rank of the template by length), so lanes that advance in step read
+// neighbouring addresses; their squared norms are precomputed on the host (tplN[row][ks]).
+// Arithmetic is identical to dtw_pair above (same ring identities), hence bit-identical scores.
+
+// (u32)sqrtf((float)d), DTW.C:59: v_sqrt_f32 is within 1 ulp; one fused-residual step against the two
+// neighbouring floats makes it the correctly rounded root (the compiler's own lowering of sqrtf minus the
+// denormal pre-scaling, which an integer-valued input never needs).
+__device__ __forceinline__ float sqrt_rn_int(float f)
+{
+    float s = __builtin_amdgcn_sqrtf(f);
+    const int si = __float_as_int(s);
+    const float s_dn = __int_as_float(si - 1), s_up = __int_as_float(si + 1);
+    const float vp = __builtin_fmaf(-s_dn, s, f), vs = __builtin_fmaf(-s_up, s, f);
+    s = (vp <= 0.0f) ? s_dn : s;
+    s = (vs > 0.0f) ? s_up : s;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
+{
+    const uint32_t d = na + nb - 2u * (uint32_t)dot;
+    return (uint32_t)sqrt_rn_int((float)d);
+}
+
+__device__ __forceinline__ int dot12(const uint2 (&a)[3], const uint2 (&b)[3])
+{
+    int acc = sdot2(a[0].x, b[0].x, 0);
+    acc = sdot2(a[0].y, b[0].y, acc);
+    acc = sdot2(a[1].x, b[1].x, acc);
+    acc = sdot2(a[1].y, b[1].y, acc);
+    acc = sdot2(a[2].x, b[2].x, acc);
+    acc = sdot2(a[2].y, b[2].y, acc);
+    return acc;
+}
+
+struct DtwLdsArgs {
+    DtwArgs d;
+    const int16_t *tplT;        // [tpl_rows][K][12], templates in length order
+    const uint32_t *tplN;       // [tpl_rows][K] squared norms (u32 wrap)
+    const uint32_t *tpl_frames_s;  // [K] frames, sorted order; 0 for invalid slots
+    const uint32_t *tpl_orig;   // [K] original slot of sorted position
+    uint32_t U;                 // utterances per workgroup
+};
+
+constexpr int kDtwMaxU = 16;
+
+__global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_n[kDtwMaxU];  // frames of the workgroup's utterances, 0 = skip
+    const uint32_t U = a.U, R = a.d.max_frames, K = a.d.K;
+    uint32_t *s_rows = smem;            // [U][R][6]
+    uint32_t *s_nrm = smem + (size_t)U * R * 6;  // [U][R]
+    const uint32_t tid = threadIdx.x, b0 = blockIdx.x * U;
+
+    if (tid < U) {
+        const uint32_t b = b0 + tid;
+        uint32_t n = 0;
+        if (b < a.d.B) {
+            if (a.d.in_frames) n = a.d.in_frames[b];
+            else n = (a.d.vad[b].status == SR_ST_OK) ? a.d.vad[b].frm_num : 0u;
+        }
+        s_n[tid] = n;
+    }
+    __syncthreads();
+    // ---- stage rows [0, min(n+1, R)) of every utterance: 24-byte rows, copied as 8-byte words ----
+    for (uint32_t u = 0; u < U; u++) {
+        const uint32_t n = s_n[u];
+        if (!n) continue;
+        const uint32_t rows = (n + 1 < R) ? n + 1 : R;
+        const uint2 *src = (const uint2 *)(a.d.mfcc + (size_t)(b0 + u) * R * kCoef);
+        uint2 *dst = (uint2 *)(s_rows + (size_t)u * R * 6);
+        for (uint32_t i = tid; i < rows * 3; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < U * R; r += blockDim.x) {
+        const uint32_t u = r / R, row = r - u * R, n = s_n[u];
+        if (n && row < ((n + 1 < R) ? n + 1 : R)) {
+            const uint2 *q = (const uint2 *)(s_rows + (size_t)r * 6);
+            const uint2 f[3] = {q[0], q[1], q[2]};
+            s_nrm[r] = (uint32_t)dot12(f, f);
+        }
+    }
+    __syncthreads();
+
+    if (tid >= U * K) return;
+    const uint32_t ks = tid / U, u = tid - ks * U, b = b0 + u;
+    if (b >= a.d.B) return;
+    const uint32_t in_n = s_n[u], mdl_n = a.tpl_frames_s[ks];
+    uint32_t score = SR_DIS_ERR;
+    if (in_n && mdl_n && !(in_n > mdl_n * 2 || 2 * in_n < mdl_n)) {  // main.c:283, DTW.C:133-137
+        const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142
+        const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
+        const uint32_t *rows_u = s_rows + (size_t)u * R * 6, *nrm_u = s_nrm + (size_t)u * R;
+        const uint32_t trows = a.d.tpl_rows;
+        uint32_t px = 0, py = 0, step = 1;
+        uint2 cm[3], nm[3];
+        uint32_t ncm, nnm;
+        {
+            const uint2 *t0 = (const uint2 *)(a.tplT + (size_t)ks * kCoef);
+            cm[0] = t0[0];
+            cm[1] = t0[1];
+            cm[2] = t0[2];
+            ncm = a.tplN[ks];
+            const uint32_t ry = (1 < trows) ? 1 : trows - 1;
+            const uint2 *t1 = (const uint2 *)(a.tplT + ((size_t)ry * K + ks) * kCoef);
+            nm[0] = t1[0];
+            nm[1] = t1[1];
+            nm[2] = t1[2];
+            nnm = a.tplN[(size_t)ry * K + ks];
+        }
+        uint32_t dis;
+        {
+            const uint2 *q = (const uint2 *)rows_u;
+            const uint2 ci[3] = {q[0], q[1], q[2]};
+            dis = dis_from(nrm_u[0], ncm, dot12(ci, cm));  // DTW.C:146
+        }
+        do {
+            const uint32_t rx = (px + 1 < R) ? px + 1 : R - 1;  // rows the do-while touches (DTW.C:150-154)
+            const uint2 *qc = (const uint2 *)(rows_u + (size_t)px * 6), *qn = (const uint2 *)(rows_u + (size_t)rx * 6);
+            const uint2 ci[3] = {qc[0], qc[1], qc[2]}, ni[3] = {qn[0], qn[1], qn[2]};
+            const uint32_t nci = nrm_u[px], nni = nrm_u[rx];
+            // dtw_limit (DTW.C:76-109) of the three candidate points, x = px+1, y = py+1
+            const int x = (int)px + 1, y = (int)py + 1;
+            const bool o_up = dtw_out(x, y + 1, X1, X2, (int)in_n, (int)mdl_n);
+            const bool o_rt = dtw_out(x + 1, y, X1, X2, (int)in_n, (int)mdl_n);
+            const bool o_dg = dtw_out(x + 1, y + 1, X1, X2, (int)in_n, (int)mdl_n);
+            const uint32_t up = o_up ? SR_DIS_ERR : dis_from(nnm, nci, dot12(nm, ci));
+            const uint32_t right = o_rt ? SR_DIS_ERR : dis_from(ncm, nni, dot12(cm, ni));
+            const uint32_t diag = o_dg ? SR_DIS_ERR : dis_from(nnm, nni, dot12(nm, ni));
+            uint32_t mn = diag;  // DTW.C:156-164
+            if (mn > right) mn = right;
+            if (mn > up) mn = up;
+            dis += mn;
+            const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
+            const bool adv_y = mv_diag || mv_up;
+            px += (mv_diag || !mv_up) ? 1u : 0u;
+            if (adv_y) {
+                py++;
+                cm[0] = nm[0];
+                cm[1] = nm[1];
+                cm[2] = nm[2];
+                ncm = nnm;
+                const uint32_t ry = (py + 1 < trows) ? py + 1 : trows - 1;
+                const uint2 *t1 = (const uint2 *)(a.tplT + ((size_t)ry * K + ks) * kCoef);
+                nm[0] = t1[0];
+                nm[1] = t1[1];
+                nm[2] = t1[2];
+                nnm = a.tplN[(size_t)ry * K + ks];
+            }
+            step = (step + 1) & 0xFFFF;
+        } while (px + 1 < in_n && py + 1 < mdl_n);  // DTW.C:188
+        score = dis / step;
+    }
+    a.d.scores[(size_t)b * K + a.tpl_orig[ks]] = score;
+}
+
+// pick U: maximise resident lanes doing useful work (LDS 160 KiB/CU, 32 waves/CU, 1024 threads/workgroup)
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes)
+{
+    uint32_t best_u = 0;
+    double best = 0;
+    for (uint32_t U = 1; U <= (uint32_t)kDtwMaxU; U++) {
+        const uint64_t pairs = (uint64_t)U * K;
+        if (pairs > 1024) break;
+        const size_t lds = (size_t)U * max_frames * 28;
+        if (lds > 64 * 1024) break;  // keep >= 2 workgroups per CU
+        const uint32_t waves = (uint32_t)((pairs + 63) / 64);
+        uint32_t blocks = (uint32_t)((160 * 1024) / (lds + 256));
+        if (blocks > 32 / waves) blocks = 32 / waves;
+        if (blocks > 8) blocks = 8;
+        const double score = (double)blocks * (double)pairs;
+        if (score > best) {
+            best = score;
+            best_u = U;
+        }
+    }
+    if (best_u && lds_bytes) *lds_bytes = (size_t)best_u * max_frames * 28;
+    return best_u;
+}
+
 void launch_dtw(const DtwArgs &a, hipStream_t s)
 {
     const uint64_t n = (uint64_t)a.B * a.K;
     if (!n) return;
-    hipLaunchKernelGGL(k_dtw, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
+    size_t lds = 0;
+    const uint32_t U = a.tplT ? dtw_lds_pick_u(a.K, a.max_frames, &lds) : 0;
+    if (U) {
+        DtwLdsArgs la{a, a.tplT, a.tplN, a.tpl_frames_s, a.tpl_orig, U};
+        const uint32_t threads = (uint32_t)(((uint64_t)U * a.K + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_dtw_lds, dim3((a.B + U - 1) / U), dim3(threads), lds, s, la);
+    } else {  // very long sequences / very many templates: generic global-memory walk
+        hipLaunchKernelGGL(k_dtw, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
+    }
 }
 
 // argmin with strict '<' in slot order (main.c:276-291): first minimum wins; all dis_err -> slot 0
