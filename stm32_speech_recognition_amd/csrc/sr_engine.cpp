@@ -375,7 +375,7 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.max_frames = h->cfg.max_frames;
     a.vad = d_vad;
     a.mfcc = d_mfcc;
-    a.tiles = (h->cfg.max_frames + 31) / 32;
+    a.tiles = (h->cfg.max_frames + 63) / 64;  // kFramesPerTile in sr_kernels.hip
     a.n_items = B * a.tiles;
     a.t = h->dev;
     return a;
@@ -385,7 +385,7 @@ int sr_mfcc_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, 
                       int16_t *d_mfcc, void *stream)
 {
     if (!h || !d_pcm || !d_vad || !d_mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
-    if ((uint64_t)B * ((h->cfg.max_frames + 31) / 32) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
+    if ((uint64_t)B * ((h->cfg.max_frames + 63) / 64) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
     HIP_TRY(hipSetDevice(h->device));
     launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, d_vad, d_mfcc), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -437,7 +437,7 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
     if (B == 0) return SR_OK;
     int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
     if (rc) return rc;
-    if ((uint64_t)B * ((h->cfg.max_frames + 31) / 32) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
+    if ((uint64_t)B * ((h->cfg.max_frames + 63) / 64) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (!d_vad) {

@@ -25,6 +25,32 @@ __device__ __forceinline__ int sext_lo(uint32_t w) { return (int)(short)(w & 0xF
 __device__ __forceinline__ int sext_hi(uint32_t w) { return (int)w >> 16; }
 __device__ __forceinline__ uint32_t pack16(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
 
+// 16-bit dot product without accumulator (VOP3P form with inline 0: no v_mov to clear a destination)
+__device__ __forceinline__ int sdot2z(uint32_t a, uint32_t b)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// full-rate 24-bit multiplies where the operands provably fit (quarter-rate v_mul_lo_u32 otherwise)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+
+// sqrtf of an integer-valued float, correctly rounded: v_sqrt_f32 is within 1 ulp; one fused-residual
+// step against the two neighbouring floats picks the correctly rounded root (the compiler's own lowering
+// of sqrtf minus the denormal pre-scaling, which an integer-valued input never needs).  Bit-identical to
+// IEEE sqrtf, hence to the reference's sqrtf calls (MFCC.C:58, DTW.C:59).
+__device__ __forceinline__ float sqrt_rn_int(float f)
+{
+    float s = __builtin_amdgcn_sqrtf(f);
+    const int si = __float_as_int(s);
+    const float s_dn = __int_as_float(si - 1), s_up = __int_as_float(si + 1);
+    const float vp = __builtin_fmaf(-s_dn, s, f), vs = __builtin_fmaf(-s_up, s, f);
+    s = (vp <= 0.0f) ? s_dn : s;
+    s = (vs > 0.0f) ? s_up : s;
+    return s;
+}
+
 // Orders LDS traffic between lanes of ONE wave: DS instructions of a wave execute in issue order, so
 // only the compiler has to be kept from moving accesses across this point.
 __device__ __forceinline__ void wave_sync()
@@ -75,8 +101,8 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 // integers, re = Yr*Kc + Yi*Ks, im = Yi*Kc - Yr*Ks with Kc = Kr'+Ki, Ks = Ki (no term overflows).
 __device__ __forceinline__ void cxmul(uint32_t y, uint32_t ka, uint32_t kb, int &re, int &im)
 {
-    re = sdot2(y, ka, 0);
-    im = sdot2(y, kb, 0);
+    re = sdot2z(y, ka);
+    im = sdot2z(y, kb);
 }
 
 // CXADDA4 (.s:105-129, S = 14) and the combine of BUTFLY4ZERO_OPT (.s:147-168, S = 0).
@@ -188,8 +214,13 @@ __device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const
         uint32_t x1 = (d2 == 0) ? y[8] : (d2 == 2) ? y[9] : 0u;   // d1 = 1 -> rows 128..159, else padding
         uint32_t x3 = 0u;                                         // d1 = 3 -> rows >= 192: padding
         int ar = sext_lo(x0), ai = 0, br = 0, bi = 0, cr, ci, dr = 0, di = 0;
-        cxmul(x2, tw.s2[1][0], tw.s2[1][1], cr, ci);
-        if (d2 == 0 || d2 == 2) cxmul(x1, tw.s2[0][0], tw.s2[0][1], br, bi);
+        // real samples: Y*conj(K) = (Yr*Kc, -Yr*Ks); tw_a = (Kc, Ks) low/high halves
+        cr = mul24(sext_lo(x2), sext_lo(tw.s2[1][0]));
+        ci = -mul24(sext_lo(x2), sext_hi(tw.s2[1][0]));
+        if (d2 == 0 || d2 == 2) {
+            br = mul24(sext_lo(x1), sext_lo(tw.s2[0][0]));
+            bi = -mul24(sext_lo(x1), sext_hi(tw.s2[0][0]));
+        }
         (void)x3;
         r4_combine<14>(ar, ai, br, bi, cr, ci, dr, di);
         v[0][d2] = pack16(ar, ai);
@@ -223,7 +254,7 @@ __device__ __forceinline__ void fft_exchange(uint32_t *buf, int lane, const uint
 // k_mfcc
 // ------------------------------------------------------------------------------------------------
 constexpr int kMfccWaves = 4;       // waves per workgroup
-constexpr int kFramesPerWave = 8;   // consecutive frames one wave turns into MFCCs per work item
+constexpr int kFramesPerWave = 16;   // consecutive frames one wave turns into MFCCs per work item
 constexpr int kFramesPerTile = kMfccWaves * kFramesPerWave;
 // per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
 constexpr int kWaveLdsWords = kXchgWords + kFrameLen + kFramesPerWave * kMel;
@@ -276,28 +307,65 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
         f_hi = (h == kMel - 1) ? kBins : (int)a.t.tri_cen[h + 1];
     }
 
-    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    // the per-utterance record of the NEXT work item is fetched while the current one is processed
+    uint32_t item = blockIdx.x;
+    uint32_t nx_nfrm = 0;
+    int nx_mid = 0, nx_seg0 = 0;
+    if (item < a.n_items) {
+        const sr_vad_rec *rec = a.vad + item / a.tiles;
+        nx_nfrm = rec->frm_num;
+        nx_mid = (int)rec->atap.mid_val;
+        nx_seg0 = rec->seg[0];
+    }
+    for (; item < a.n_items; item += gridDim.x) {
         const uint32_t b = item / a.tiles, tile = item - b * a.tiles;
-        const sr_vad_rec *rec = a.vad + b;
-        const uint32_t nfrm = rec->frm_num;
-        const int mid = (int)rec->atap.mid_val;
-        const int seg0 = rec->seg[0];
+        const uint32_t nfrm = nx_nfrm;
+        const int mid = nx_mid, seg0 = nx_seg0;
+        if (item + gridDim.x < a.n_items) {
+            const sr_vad_rec *rec = a.vad + (item + gridDim.x) / a.tiles;
+            nx_nfrm = rec->frm_num;
+            nx_mid = (int)rec->atap.mid_val;
+            nx_seg0 = rec->seg[0];
+        }
         const uint16_t *row = a.pcm + (uint64_t)b * a.pcm_stride;
         int16_t *out = a.mfcc + (uint64_t)b * a.max_frames * kCoef;
         const uint32_t f0 = tile * kFramesPerTile + w * kFramesPerWave;
         uint32_t nf = 0;  // frames this wave really has
         if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFramesPerWave) ? nfrm - f0 : (uint32_t)kFramesPerWave;
 
+        // samples of frame fi+1 are requested while frame fi is transformed
+        int s_cur[3] = {0, 0, 0}, s_prv[3] = {0, 0, 0};
+        if (nf) {
+            const uint16_t *x = row + seg0 + (int)kHop * (int)f0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int i = lane + 64 * k;
+                if (i < kFrameLen) {
+                    s_cur[k] = x[i];
+                    s_prv[k] = x[i - 1];
+                }
+            }
+        }
         for (uint32_t fi = 0; fi < nf; fi++) {
-            const uint16_t *x = row + seg0 + (int)kHop * (int)(f0 + fi);
             // ---- pre-emphasis + Hamming (MFCC.C:115-124); x[-1] is the sample before the frame
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int i = lane + 64 * k;
                 if (i < kFrameLen) {
-                    const int cur = (int)x[i] - mid, prv = (int)x[i - 1] - mid;
-                    const int t = cur - prv * 95 / 100;
-                    xw[i] = (int)(short)(t * hamm_r[k] / 1000);
+                    const int cur = s_cur[k] - mid, prv = s_prv[k] - mid;
+                    const int t = cur - mul24(prv, 95) / 100;
+                    xw[i] = (int)(short)(mul24(t, hamm_r[k]) / 1000);
+                }
+            }
+            if (fi + 1 < nf) {
+                const uint16_t *x = row + seg0 + (int)kHop * (int)(f0 + fi + 1);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int i = lane + 64 * k;
+                    if (i < kFrameLen) {
+                        s_cur[k] = x[i];
+                        s_prv[k] = x[i - 1];
+                    }
                 }
             }
             wave_sync();
@@ -322,9 +390,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
                     const int re = (int)(short)(o ? br : ar), im = (int)(short)(o ? bi : ai);
-                    const int r = re * re + im * im;
-                    const uint32_t mag = (uint32_t)(sqrtf((float)r) * 10.0f);
-                    buf[lane + 64 * e3 + 256 * o] = mag * mag;
+                    const int r = mul24(re, re) + mul24(im, im);
+                    const uint32_t mag = (uint32_t)(sqrt_rn_int((float)r) * 10.0f);  // < 2^19
+                    buf[lane + 64 * e3 + 256 * o] = umul24(mag, mag);
                 }
             }
             wave_sync();
@@ -369,7 +437,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
             const uint32_t fi = t / kCoef, h = t - fi * kCoef;
             int acc = 0;
 #pragma unroll
-            for (int i = 0; i < kMel; i++) acc += (int)powb[fi * kMel + i] * (int)s_dct[h * kMel + i] / 100;
+            for (int i = 0; i < kMel; i++) acc += mul24((int)powb[fi * kMel + i], (int)s_dct[h * kMel + i]) / 100;
             out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
         }
         wave_sync();
@@ -384,7 +452,19 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
 void launch_mfcc(const MfccArgs &a, hipStream_t s)
 {
     if (a.n_items == 0) return;
-    const uint32_t cap = 256u * 8u;  // persistent-style grid: a few workgroups per CU, items strided
+    // persistent-style grid: exactly the workgroups that are resident at once, work items strided
+    static int per_cu = 0, n_cu = 0;
+    if (!per_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc, 64 * kMfccWaves,
+                                                         (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t)) != hipSuccess ||
+            per_cu < 1)
+            per_cu = 2;
+        if (n_cu < 1) n_cu = 256;
+    }
+    const uint32_t cap = (uint32_t)(per_cu * n_cu);
     const uint32_t grid = a.n_items < cap ? a.n_items : cap;
     const size_t lds = (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t);
     hipLaunchKernelGGL(k_mfcc, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
@@ -811,20 +891,6 @@ __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
 // tplT[row][ks][12] (ks = rank of the template by length), so lanes that advance in step read
 // neighbouring addresses; their squared norms are precomputed on the host (tplN[row][ks]).
 // Arithmetic is identical to dtw_pair above (same ring identities), hence bit-identical scores.
-
-// (u32)sqrtf((float)d), DTW.C:59: v_sqrt_f32 is within 1 ulp; one fused-residual step against the two
-// neighbouring floats makes it the correctly rounded root (the compiler's own lowering of sqrtf minus the
-// denormal pre-scaling, which an integer-valued input never needs).
-__device__ __forceinline__ float sqrt_rn_int(float f)
-{
-    float s = __builtin_amdgcn_sqrtf(f);
-    const int si = __float_as_int(s);
-    const float s_dn = __int_as_float(si - 1), s_up = __int_as_float(si + 1);
-    const float vp = __builtin_fmaf(-s_dn, s, f), vs = __builtin_fmaf(-s_up, s, f);
-    s = (vp <= 0.0f) ? s_dn : s;
-    s = (vs > 0.0f) ? s_up : s;
-    return s;
-}
 
 __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
 {
