@@ -900,7 +900,7 @@ __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
 
 __device__ __forceinline__ int dot12(const uint2 (&a)[3], const uint2 (&b)[3])
 {
-    int acc = sdot2(a[0].x, b[0].x, 0);
+    int acc = sdot2z(a[0].x, b[0].x);
     acc = sdot2(a[0].y, b[0].y, acc);
     acc = sdot2(a[1].x, b[1].x, acc);
     acc = sdot2(a[1].y, b[1].y, acc);
@@ -967,65 +967,79 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
     if (in_n && mdl_n && !(in_n > mdl_n * 2 || 2 * in_n < mdl_n)) {  // main.c:283, DTW.C:133-137
         const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142
         const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
-        const uint32_t *rows_u = s_rows + (size_t)u * R * 6, *nrm_u = s_nrm + (size_t)u * R;
-        const uint32_t trows = a.d.tpl_rows;
-        uint32_t px = 0, py = 0, step = 1;
+        // dtw_limit (DTW.C:76-109) in the variables uu = y - 2x, ww = 2y - x of a point (x, y):
+        //   outside  <=>  (x < X1 ? uu >= 2 : ww >= t1)  ||  (x < X2 ? ww <= -2 : uu <= t2)
+        const int t1 = 4 - ((int)in_n - 2 * (int)mdl_n), t2 = ((int)mdl_n - 2 * (int)in_n) - 4;
+        // byte cursors: current input row in LDS, NEXT template row in HBM; rows px+1 / py+1 always exist
+        // inside the loop (px+1 < in_n <= R and py+1 < mdl_n < tpl_rows; for 1-frame sequences row 1 is the
+        // slack row the reference's do-while reads, DTW.C:150-154)
+        const char *in_p = (const char *)(s_rows + (size_t)u * R * 6);
+        const uint32_t *nrm_p = s_nrm + (size_t)u * R;
+        const uint32_t t_stride = K * (kCoef * 2);
+        const char *tp = (const char *)a.tplT + (size_t)ks * (kCoef * 2);
+        const uint32_t *tn = a.tplN + ks;
         uint2 cm[3], nm[3];
         uint32_t ncm, nnm;
-        {
-            const uint2 *t0 = (const uint2 *)(a.tplT + (size_t)ks * kCoef);
-            cm[0] = t0[0];
-            cm[1] = t0[1];
-            cm[2] = t0[2];
-            ncm = a.tplN[ks];
-            const uint32_t ry = (1 < trows) ? 1 : trows - 1;
-            const uint2 *t1 = (const uint2 *)(a.tplT + ((size_t)ry * K + ks) * kCoef);
-            nm[0] = t1[0];
-            nm[1] = t1[1];
-            nm[2] = t1[2];
-            nnm = a.tplN[(size_t)ry * K + ks];
-        }
+        cm[0] = ((const uint2 *)tp)[0];
+        cm[1] = ((const uint2 *)tp)[1];
+        cm[2] = ((const uint2 *)tp)[2];
+        ncm = tn[0];
+        tp += t_stride;
+        tn += K;
+        nm[0] = ((const uint2 *)tp)[0];
+        nm[1] = ((const uint2 *)tp)[1];
+        nm[2] = ((const uint2 *)tp)[2];
+        nnm = tn[0];
         uint32_t dis;
         {
-            const uint2 *q = (const uint2 *)rows_u;
+            const uint2 *q = (const uint2 *)in_p;
             const uint2 ci[3] = {q[0], q[1], q[2]};
-            dis = dis_from(nrm_u[0], ncm, dot12(ci, cm));  // DTW.C:146
+            dis = dis_from(nrm_p[0], ncm, dot12(ci, cm));  // DTW.C:146
         }
+        int x = 1, y = 1, uu = -1, ww = 1;  // x = y = 1 (DTW.C:147-148)
+        uint32_t step = 1;
         do {
-            const uint32_t rx = (px + 1 < R) ? px + 1 : R - 1;  // rows the do-while touches (DTW.C:150-154)
-            const uint2 *qc = (const uint2 *)(rows_u + (size_t)px * 6), *qn = (const uint2 *)(rows_u + (size_t)rx * 6);
-            const uint2 ci[3] = {qc[0], qc[1], qc[2]}, ni[3] = {qn[0], qn[1], qn[2]};
-            const uint32_t nci = nrm_u[px], nni = nrm_u[rx];
-            // dtw_limit (DTW.C:76-109) of the three candidate points, x = px+1, y = py+1
-            const int x = (int)px + 1, y = (int)py + 1;
-            const bool o_up = dtw_out(x, y + 1, X1, X2, (int)in_n, (int)mdl_n);
-            const bool o_rt = dtw_out(x + 1, y, X1, X2, (int)in_n, (int)mdl_n);
-            const bool o_dg = dtw_out(x + 1, y + 1, X1, X2, (int)in_n, (int)mdl_n);
-            const uint32_t up = o_up ? SR_DIS_ERR : dis_from(nnm, nci, dot12(nm, ci));
-            const uint32_t right = o_rt ? SR_DIS_ERR : dis_from(ncm, nni, dot12(cm, ni));
-            const uint32_t diag = o_dg ? SR_DIS_ERR : dis_from(nnm, nni, dot12(nm, ni));
+            const uint2 *q = (const uint2 *)in_p;
+            const uint2 ci[3] = {q[0], q[1], q[2]}, ni[3] = {q[3], q[4], q[5]};
+            const uint32_t nci = nrm_p[0], nni = nrm_p[1];
+            // all three candidate distances, unconditionally (branch-free; masked to dis_err below)
+            const uint32_t d_up = dis_from(nnm, nci, dot12(nm, ci));   // (x, y+1):   get_dis(mdl+12, in)
+            const uint32_t d_rt = dis_from(ncm, nni, dot12(cm, ni));   // (x+1, y):   get_dis(mdl, in+12)
+            const uint32_t d_dg = dis_from(nnm, nni, dot12(nm, ni));   // (x+1, y+1)
+            const bool xa1 = x < X1, xa2 = x < X2, xb1 = x + 1 < X1, xb2 = x + 1 < X2;
+            const bool o_up = (xa1 ? (uu + 1 >= 2) : (ww + 2 >= t1)) || (xa2 ? (ww + 2 <= -2) : (uu + 1 <= t2));
+            const bool o_rt = (xb1 ? (uu - 2 >= 2) : (ww - 1 >= t1)) || (xb2 ? (ww - 1 <= -2) : (uu - 2 <= t2));
+            const bool o_dg = (xb1 ? (uu - 1 >= 2) : (ww + 1 >= t1)) || (xb2 ? (ww + 1 <= -2) : (uu - 1 <= t2));
+            const uint32_t up = o_up ? SR_DIS_ERR : d_up, right = o_rt ? SR_DIS_ERR : d_rt,
+                           diag = o_dg ? SR_DIS_ERR : d_dg;
             uint32_t mn = diag;  // DTW.C:156-164
             if (mn > right) mn = right;
             if (mn > up) mn = up;
             dis += mn;
             const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
-            const bool adv_y = mv_diag || mv_up;
-            px += (mv_diag || !mv_up) ? 1u : 0u;
+            const bool adv_y = mv_diag || mv_up, adv_x = mv_diag || !mv_up;
+            if (adv_x) {
+                x++;
+                in_p += kCoef * 2;
+                nrm_p++;
+            }
             if (adv_y) {
-                py++;
+                y++;
                 cm[0] = nm[0];
                 cm[1] = nm[1];
                 cm[2] = nm[2];
                 ncm = nnm;
-                const uint32_t ry = (py + 1 < trows) ? py + 1 : trows - 1;
-                const uint2 *t1 = (const uint2 *)(a.tplT + ((size_t)ry * K + ks) * kCoef);
-                nm[0] = t1[0];
-                nm[1] = t1[1];
-                nm[2] = t1[2];
-                nnm = a.tplN[(size_t)ry * K + ks];
+                tp += t_stride;
+                tn += K;
+                nm[0] = ((const uint2 *)tp)[0];
+                nm[1] = ((const uint2 *)tp)[1];
+                nm[2] = ((const uint2 *)tp)[2];
+                nnm = tn[0];
             }
+            uu = y - 2 * x;
+            ww = 2 * y - x;
             step = (step + 1) & 0xFFFF;
-        } while (px + 1 < in_n && py + 1 < mdl_n);  // DTW.C:188
+        } while (x < (int)in_n && y < (int)mdl_n);  // DTW.C:188
         score = dis / step;
     }
     a.d.scores[(size_t)b * K + a.tpl_orig[ks]] = score;
