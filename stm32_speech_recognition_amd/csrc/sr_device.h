@@ -61,8 +61,7 @@ struct DtwArgs {
     uint32_t *scores;         // [B][K]
     sr_result *results;       // [B] (argmin kernel)
     // length-sorted, row-interleaved copy of the store for k_dtw_lds (NULL -> generic kernel)
-    const int16_t *tplT;          // [tpl_rows][K][12]
-    const uint32_t *tplN;         // [tpl_rows][K]
+    const void *tplR;             // [tpl_rows][K] 32-byte rows: 12 x s16 | u32 squared norm | pad
     const uint32_t *tpl_frames_s; // [K]
     const uint32_t *tpl_orig;     // [K]
 };

@@ -65,8 +65,8 @@ struct sr_engine {
     DevBuf<int16_t> tpl;
     DevBuf<uint32_t> tpl_frames;
     DevBuf<uint8_t> tpl_valid;
-    DevBuf<int16_t> tplT;          // [rows][K][12], templates ordered by length (k_dtw_lds)
-    DevBuf<uint32_t> tplN, tpl_frames_s, tpl_orig;
+    DevBuf<uint32_t> tplR;         // [rows][K] 32-byte rows (12 x s16 | norm | pad), templates ordered by length
+    DevBuf<uint32_t> tpl_frames_s, tpl_orig;
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
@@ -188,8 +188,7 @@ void sr_destroy(sr_engine *h)
     h->tpl.release();
     h->tpl_frames.release();
     h->tpl_valid.release();
-    h->tplT.release();
-    h->tplN.release();
+    h->tplR.release();
     h->tpl_frames_s.release();
     h->tpl_orig.release();
     h->s_pcm.release();
@@ -226,25 +225,23 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
             const uint32_t fx = v[x] ? f[x] : 0xFFFFFFFFu, fy = v[y] ? f[y] : 0xFFFFFFFFu;
             return fx < fy;
         });
-        std::vector<int16_t> mt((size_t)rows * K * kCoef);
-        std::vector<uint32_t> nt((size_t)rows * K), fs(K);
+        std::vector<uint32_t> rt((size_t)rows * K * 8, 0u), fs(K);
         for (uint32_t ks = 0; ks < K; ks++) {
             const uint32_t k = order[ks];
             fs[ks] = v[k] ? f[k] : 0u;
             for (uint32_t r = 0; r < rows; r++) {
                 const int16_t *src = &m[((size_t)k * rows + r) * kCoef];
-                std::memcpy(&mt[((size_t)r * K + ks) * kCoef], src, kCoef * 2);
+                uint32_t *dst = &rt[((size_t)r * K + ks) * 8];
+                std::memcpy(dst, src, kCoef * 2);
                 uint32_t nrm = 0;
                 for (int c = 0; c < kCoef; c++) nrm += (uint32_t)((int32_t)src[c] * (int32_t)src[c]);
-                nt[(size_t)r * K + ks] = nrm;
+                dst[6] = nrm;
             }
         }
-        if ((rc = h->tplT.reserve(mt.size()))) return rc;
-        if ((rc = h->tplN.reserve(nt.size()))) return rc;
+        if ((rc = h->tplR.reserve(rt.size()))) return rc;
         if ((rc = h->tpl_frames_s.reserve(K))) return rc;
         if ((rc = h->tpl_orig.reserve(K))) return rc;
-        HIP_TRY(hipMemcpy(h->tplT.p, mt.data(), mt.size() * 2, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->tplN.p, nt.data(), nt.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->tplR.p, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->tpl_frames_s.p, fs.data(), K * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->tpl_orig.p, order.data(), K * 4, hipMemcpyHostToDevice));
     }
@@ -409,8 +406,7 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.tpl_rows = h->tpl_rows;
     a.scores = d_scores;
     a.results = d_results;
-    a.tplT = h->tplT.p;
-    a.tplN = h->tplN.p;
+    a.tplR = h->tplR.p;
     a.tpl_frames_s = h->tpl_frames_s.p;
     a.tpl_orig = h->tpl_orig.p;
     return a;

@@ -6,12 +6,17 @@
 //   k_mfcc    get_mfcc (MFCC.C:86-191) incl. fft (MFCC.C:27-62) and cr4_fft_1024_stm32 (.s:95-281)
 //   k_dtw     dtw / get_dis / dtw_limit (DTW.C:45-192) for every (utterance, template) pair
 //   k_argmin  the template scan of spch_recg (main.c:276-295)
+#include <cstdlib>
+
 #include "sr_device.h"
 #include "sr_tables.h"
 
 namespace sr {
 
 typedef short short2v __attribute__((ext_vector_type(2)));
+// native vector types: one load instruction of exactly this width (HIP's uint2/uint4 structs get re-split)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -911,22 +916,57 @@ __device__ __forceinline__ int dot12(const uint2 (&a)[3], const uint2 (&b)[3])
 
 struct DtwLdsArgs {
     DtwArgs d;
-    const int16_t *tplT;        // [tpl_rows][K][12], templates in length order
-    const uint32_t *tplN;       // [tpl_rows][K] squared norms (u32 wrap)
+    const u32x4 *tplR;          // [tpl_rows][K] 32-byte rows: 12 x s16 | u32 squared norm | pad ; length order
     const uint32_t *tpl_frames_s;  // [K] frames, sorted order; 0 for invalid slots
     const uint32_t *tpl_orig;   // [K] original slot of sorted position
     uint32_t U;                 // utterances per workgroup
 };
 
 constexpr int kDtwMaxU = 16;
+// words between utterances in the LDS image: rows are 6 words; the stride is the next value == 22 (mod 64)
+// so that equal rows of different utterances do not alias (64 banks for 8-byte reads); norms: == 11 (mod 32)
+__host__ __device__ inline uint32_t dtw_lds_row_stride(uint32_t R)
+{
+    uint32_t s = R * 6;
+    return s + ((22 + 64 - (s & 63)) & 63);
+}
+__host__ __device__ inline uint32_t dtw_lds_nrm_stride(uint32_t R) { return R + ((11 + 32 - (R & 31)) & 31); }
+
+// 32-byte feature row: w[0..5] = 12 x s16, w[6] = squared norm (u32 wrap), w[7] unused
+struct Row32 {
+    uint32_t w[8];
+};
+__device__ __forceinline__ Row32 row_from(const u32x4 lo, const u32x4 hi)
+{
+    Row32 r;
+    r.w[0] = lo.x; r.w[1] = lo.y; r.w[2] = lo.z; r.w[3] = lo.w;
+    r.w[4] = hi.x; r.w[5] = hi.y; r.w[6] = hi.z; r.w[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ Row32 row_from2(const u32x2 a, const u32x2 b, const u32x2 c, uint32_t nrm)
+{
+    Row32 r;
+    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = b.x; r.w[3] = b.y; r.w[4] = c.x; r.w[5] = c.y;
+    r.w[6] = nrm; r.w[7] = 0;
+    return r;
+}
+__device__ __forceinline__ int dot_rows(const Row32 &a, const Row32 &b)
+{
+    int acc = sdot2z(a.w[0], b.w[0]);
+#pragma unroll
+    for (int i = 1; i < 6; i++) acc = sdot2(a.w[i], b.w[i], acc);
+    return acc;
+}
 
 __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    extern __shared__ __attribute__((aligned(16))) u32x2 smem2[];  // 8-byte typed: rows are read as ds_read_b64
     __shared__ uint32_t s_n[kDtwMaxU];  // frames of the workgroup's utterances, 0 = skip
     const uint32_t U = a.U, R = a.d.max_frames, K = a.d.K;
-    uint32_t *s_rows = smem;            // [U][R][6]
-    uint32_t *s_nrm = smem + (size_t)U * R * 6;  // [U][R]
+    // LDS image: 24-byte rows (3 x 8 bytes) + a separate array of squared norms.  Strides are padded so that
+    // lanes sitting on the same row of different utterances fall on different banks.
+    const uint32_t row_stride = dtw_lds_row_stride(R), nrm_stride = dtw_lds_nrm_stride(R);  // words
+    uint32_t *s_nrm = (uint32_t *)(smem2 + (size_t)U * (row_stride / 2));
     const uint32_t tid = threadIdx.x, b0 = blockIdx.x * U;
 
     if (tid < U) {
@@ -939,22 +979,25 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         s_n[tid] = n;
     }
     __syncthreads();
-    // ---- stage rows [0, min(n+1, R)) of every utterance: 24-byte rows, copied as 8-byte words ----
+    // ---- stage rows [0, min(n+1, R)) of every utterance and their squared norms ----
     for (uint32_t u = 0; u < U; u++) {
         const uint32_t n = s_n[u];
         if (!n) continue;
         const uint32_t rows = (n + 1 < R) ? n + 1 : R;
         const uint2 *src = (const uint2 *)(a.d.mfcc + (size_t)(b0 + u) * R * kCoef);
-        uint2 *dst = (uint2 *)(s_rows + (size_t)u * R * 6);
-        for (uint32_t i = tid; i < rows * 3; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-    for (uint32_t r = tid; r < U * R; r += blockDim.x) {
-        const uint32_t u = r / R, row = r - u * R, n = s_n[u];
-        if (n && row < ((n + 1 < R) ? n + 1 : R)) {
-            const uint2 *q = (const uint2 *)(s_rows + (size_t)r * 6);
-            const uint2 f[3] = {q[0], q[1], q[2]};
-            s_nrm[r] = (uint32_t)dot12(f, f);
+        u32x2 *dst = smem2 + (size_t)u * (row_stride / 2);
+        for (uint32_t r = tid; r < rows; r += blockDim.x) {
+            const uint2 q0 = src[3 * r], q1 = src[3 * r + 1], q2 = src[3 * r + 2];
+            int nr = sdot2z(q0.x, q0.x);
+            nr = sdot2(q0.y, q0.y, nr);
+            nr = sdot2(q1.x, q1.x, nr);
+            nr = sdot2(q1.y, q1.y, nr);
+            nr = sdot2(q2.x, q2.x, nr);
+            nr = sdot2(q2.y, q2.y, nr);
+            dst[3 * r] = u32x2{q0.x, q0.y};
+            dst[3 * r + 1] = u32x2{q1.x, q1.y};
+            dst[3 * r + 2] = u32x2{q2.x, q2.y};
+            s_nrm[u * nrm_stride + r] = (uint32_t)nr;
         }
     }
     __syncthreads();
@@ -970,42 +1013,30 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         // dtw_limit (DTW.C:76-109) in the variables uu = y - 2x, ww = 2y - x of a point (x, y):
         //   outside  <=>  (x < X1 ? uu >= 2 : ww >= t1)  ||  (x < X2 ? ww <= -2 : uu <= t2)
         const int t1 = 4 - ((int)in_n - 2 * (int)mdl_n), t2 = ((int)mdl_n - 2 * (int)in_n) - 4;
-        // byte cursors: current input row in LDS, NEXT template row in HBM; rows px+1 / py+1 always exist
-        // inside the loop (px+1 < in_n <= R and py+1 < mdl_n < tpl_rows; for 1-frame sequences row 1 is the
-        // slack row the reference's do-while reads, DTW.C:150-154)
-        const char *in_p = (const char *)(s_rows + (size_t)u * R * 6);
-        const uint32_t *nrm_p = s_nrm + (size_t)u * R;
-        const uint32_t t_stride = K * (kCoef * 2);
-        const char *tp = (const char *)a.tplT + (size_t)ks * (kCoef * 2);
-        const uint32_t *tn = a.tplN + ks;
-        uint2 cm[3], nm[3];
-        uint32_t ncm, nnm;
-        cm[0] = ((const uint2 *)tp)[0];
-        cm[1] = ((const uint2 *)tp)[1];
-        cm[2] = ((const uint2 *)tp)[2];
-        ncm = tn[0];
+        // cursors: current input row in LDS, NEXT template row in HBM; rows px+1 / py+1 always exist inside the
+        // loop (px+1 < in_n <= R and py+1 < mdl_n < tpl_rows; for 1-frame sequences row 1 is the slack row the
+        // reference's do-while reads, DTW.C:150-154)
+        const u32x2 *in_p = smem2 + (size_t)u * (row_stride / 2);
+        const uint32_t *nrm_p = s_nrm + (size_t)u * nrm_stride;
+        const u32x4 *tp = a.tplR + (size_t)ks * 2;
+        const uint32_t t_stride = K * 2;  // uint4 per template row level
+        Row32 cm = row_from(tp[0], tp[1]);
         tp += t_stride;
-        tn += K;
-        nm[0] = ((const uint2 *)tp)[0];
-        nm[1] = ((const uint2 *)tp)[1];
-        nm[2] = ((const uint2 *)tp)[2];
-        nnm = tn[0];
+        Row32 nm = row_from(tp[0], tp[1]);
         uint32_t dis;
         {
-            const uint2 *q = (const uint2 *)in_p;
-            const uint2 ci[3] = {q[0], q[1], q[2]};
-            dis = dis_from(nrm_p[0], ncm, dot12(ci, cm));  // DTW.C:146
+            const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]);
+            dis = dis_from(ci.w[6], cm.w[6], dot_rows(ci, cm));  // DTW.C:146
         }
         int x = 1, y = 1, uu = -1, ww = 1;  // x = y = 1 (DTW.C:147-148)
         uint32_t step = 1;
         do {
-            const uint2 *q = (const uint2 *)in_p;
-            const uint2 ci[3] = {q[0], q[1], q[2]}, ni[3] = {q[3], q[4], q[5]};
-            const uint32_t nci = nrm_p[0], nni = nrm_p[1];
+            const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]),
+                        ni = row_from2(in_p[3], in_p[4], in_p[5], nrm_p[1]);
             // all three candidate distances, unconditionally (branch-free; masked to dis_err below)
-            const uint32_t d_up = dis_from(nnm, nci, dot12(nm, ci));   // (x, y+1):   get_dis(mdl+12, in)
-            const uint32_t d_rt = dis_from(ncm, nni, dot12(cm, ni));   // (x+1, y):   get_dis(mdl, in+12)
-            const uint32_t d_dg = dis_from(nnm, nni, dot12(nm, ni));   // (x+1, y+1)
+            const uint32_t d_up = dis_from(nm.w[6], ci.w[6], dot_rows(nm, ci));  // (x, y+1):   get_dis(mdl+12, in)
+            const uint32_t d_rt = dis_from(cm.w[6], ni.w[6], dot_rows(cm, ni));  // (x+1, y):   get_dis(mdl, in+12)
+            const uint32_t d_dg = dis_from(nm.w[6], ni.w[6], dot_rows(nm, ni));  // (x+1, y+1)
             const bool xa1 = x < X1, xa2 = x < X2, xb1 = x + 1 < X1, xb2 = x + 1 < X2;
             const bool o_up = (xa1 ? (uu + 1 >= 2) : (ww + 2 >= t1)) || (xa2 ? (ww + 2 <= -2) : (uu + 1 <= t2));
             const bool o_rt = (xb1 ? (uu - 2 >= 2) : (ww - 1 >= t1)) || (xb2 ? (ww - 1 <= -2) : (uu - 2 <= t2));
@@ -1020,21 +1051,14 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             const bool adv_y = mv_diag || mv_up, adv_x = mv_diag || !mv_up;
             if (adv_x) {
                 x++;
-                in_p += kCoef * 2;
+                in_p += 3;
                 nrm_p++;
             }
             if (adv_y) {
                 y++;
-                cm[0] = nm[0];
-                cm[1] = nm[1];
-                cm[2] = nm[2];
-                ncm = nnm;
+                cm = nm;
                 tp += t_stride;
-                tn += K;
-                nm[0] = ((const uint2 *)tp)[0];
-                nm[1] = ((const uint2 *)tp)[1];
-                nm[2] = ((const uint2 *)tp)[2];
-                nnm = tn[0];
+                nm = row_from(tp[0], tp[1]);
             }
             uu = y - 2 * x;
             ww = 2 * y - x;
@@ -1048,24 +1072,32 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 // pick U: maximise resident lanes doing useful work (LDS 160 KiB/CU, 32 waves/CU, 1024 threads/workgroup)
 uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes)
 {
+    // The kernel is VALU-bound, so what counts is the fraction of lanes that carry a pair
+    // (U*K / (64*waves)), as long as enough waves stay resident per CU to cover LDS/L2 latency.
+    const size_t per_u = (size_t)(dtw_lds_row_stride(max_frames) + dtw_lds_nrm_stride(max_frames)) * 4;
     uint32_t best_u = 0;
     double best = 0;
+    const char *force = getenv("SR_DTW_U");  // tuning override
     for (uint32_t U = 1; U <= (uint32_t)kDtwMaxU; U++) {
         const uint64_t pairs = (uint64_t)U * K;
         if (pairs > 1024) break;
-        const size_t lds = (size_t)U * max_frames * 28;
-        if (lds > 64 * 1024) break;  // keep >= 2 workgroups per CU
+        const size_t lds = U * per_u;
+        if (lds > 150 * 1024) break;
         const uint32_t waves = (uint32_t)((pairs + 63) / 64);
-        uint32_t blocks = (uint32_t)((160 * 1024) / (lds + 256));
+        uint32_t blocks = (uint32_t)((160 * 1024) / (lds + 512));
         if (blocks > 32 / waves) blocks = 32 / waves;
         if (blocks > 8) blocks = 8;
-        const double score = (double)blocks * (double)pairs;
-        if (score > best) {
+        if (blocks < 1) continue;
+        const double eff = (double)pairs / (64.0 * waves);
+        const double resident = (double)(blocks * waves);
+        double score = eff * (resident >= 24 ? 1.0 : resident / 24.0);
+        if (force && (uint32_t)atoi(force) == U) score = 100.0;
+        if (score > best + 1e-9) {
             best = score;
             best_u = U;
         }
     }
-    if (best_u && lds_bytes) *lds_bytes = (size_t)best_u * max_frames * 28;
+    if (best_u && lds_bytes) *lds_bytes = best_u * per_u;
     return best_u;
 }
 
@@ -1074,9 +1106,9 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
     const uint64_t n = (uint64_t)a.B * a.K;
     if (!n) return;
     size_t lds = 0;
-    const uint32_t U = a.tplT ? dtw_lds_pick_u(a.K, a.max_frames, &lds) : 0;
+    const uint32_t U = a.tplR ? dtw_lds_pick_u(a.K, a.max_frames, &lds) : 0;
     if (U) {
-        DtwLdsArgs la{a, a.tplT, a.tplN, a.tpl_frames_s, a.tpl_orig, U};
+        DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U};
         const uint32_t threads = (uint32_t)(((uint64_t)U * a.K + 63) / 64 * 64);
         hipLaunchKernelGGL(k_dtw_lds, dim3((a.B + U - 1) / U), dim3(threads), lds, s, la);
     } else {  // very long sequences / very many templates: generic global-memory walk
