@@ -56,6 +56,41 @@ __device__ __forceinline__ float sqrt_rn_int(float f)
     return s;
 }
 
+// ---- packed 16+16-bit helpers (VOP3P): one instruction works on the real and imaginary halves ----
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_ashr(uint32_t a, int n)
+{
+    return __builtin_bit_cast(uint32_t, (short2v)(__builtin_bit_cast(short2v, a) >> (short2v){(short)n, (short)n}));
+}
+__device__ __forceinline__ uint32_t pk_lshr(uint32_t a, int n)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) >> (u16x2){(unsigned short)n, (unsigned short)n}));
+}
+// a*c + b per half (v_pk_mad_u16); c is a packed constant such as (+1, -1)
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t c, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, c) +
+                                                __builtin_bit_cast(u16x2, b)));
+}
+// (hi16(lo_src) , hi16(hi_src)) -> packed word: the ">>16" of a complex 32-bit pair in ONE v_perm_b32
+__device__ __forceinline__ uint32_t pk_hi16(int lo_src, int hi_src)
+{
+    return __builtin_amdgcn_perm((uint32_t)hi_src, (uint32_t)lo_src, 0x07060302u);
+}
+// bit 15 of each source in bit 0 of the matching half: (x >> 15) = 2*(x >> 16) + this
+__device__ __forceinline__ uint32_t pk_bit15(int lo_src, int hi_src)
+{
+    return pk_lshr(__builtin_amdgcn_perm((uint32_t)hi_src, (uint32_t)lo_src, 0x0C050C01u), 7);
+}
+
 // Orders LDS traffic between lanes of ONE wave: DS instructions of a wave execute in issue order, so
 // only the compiler has to be kept from moving accesses across this point.
 __device__ __forceinline__ void wave_sync()
@@ -138,19 +173,54 @@ __device__ __forceinline__ void r4_combine(int &ar, int &ai, int &br, int &bi, i
 }
 
 // One twiddled butterfly on packed words; k* = packed coefficient pairs for the legs j+q, j+2q, j+3q.
-// Results are re-packed to 16+16 bits, which is the STRH truncation of .s:194-204.
-__device__ __forceinline__ void bfly(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, uint32_t k1a, uint32_t k1b,
-                                     uint32_t k2a, uint32_t k2b, uint32_t k3a, uint32_t k3b)
+// CXADDA4 (.s:105-129) in packed 16-bit arithmetic.  Every value the asm stores is the low 16 bits of a
+// 32-bit sum of terms (A>>2), (X>>16), (X>>15); sums mod 2^16 may be taken in any order, and
+// (X>>15) = 2*(X>>16) + bit15(X), so with h = X>>16, e = bit15(X) (both halves at once):
+//   A1 = a + hB          B1 = A1 - (B>>15) = a - hB - eB
+//   A2 = A1 + hC'        C2 = A2 - (C'>>15) = A1 - hC' - eC'
+//   B2 = B1 + S*hD'~     D2 = B2 - S*(D'>>15)~ = B1 - S*(hD'~ + eD'~)      S = (+1,-1), ~ = halves swapped
+// (.s:125-128: Br += Di>>16, Bi -= Dr>>16, Di = Br - Di>>15, Dr = Bi + Dr>>15, stored as (Di, Dr)).
+constexpr uint32_t kPkPlusMinus = 0xFFFF0001u;  // (+1, -1)
+constexpr uint32_t kPkMinusPlus = 0x0001FFFFu;  // (-1, +1)
+
+// combine step on 32-bit products B, C' = C+D, D' = C-D and the packed sample A
+template <bool HALF, bool HAS_B>
+__device__ __forceinline__ void r4_packed(uint32_t x0_in, int br, int bi, int sr, int si, int tr, int ti, uint32_t &x0,
+                                          uint32_t &x1, uint32_t &x2, uint32_t &x3)
 {
-    int ar = sext_lo(x0), ai = sext_hi(x0), br, bi, cr, ci, dr, di;
+    const uint32_t a = pk_ashr(x0_in, 2);
+    uint32_t A1 = a, B1 = a;
+    if (HAS_B) {
+        const uint32_t hB = pk_hi16(br, bi), eB = pk_bit15(br, bi);
+        A1 = pk_add(a, hB);
+        B1 = pk_sub(pk_sub(a, hB), eB);
+    }
+    const uint32_t hC = pk_hi16(sr, si);
+    const uint32_t hD = pk_hi16(ti, tr);  // swapped: (D'i>>16, D'r>>16)
+    x0 = pk_add(A1, hC);
+    x1 = pk_mad(hD, kPkPlusMinus, B1);
+    if (!HALF) {
+        const uint32_t eC = pk_bit15(sr, si), eD = pk_bit15(ti, tr);
+        x2 = pk_sub(pk_sub(A1, hC), eC);
+        x3 = pk_mad(pk_add(hD, eD), kPkMinusPlus, B1);
+    }
+}
+
+template <bool HALF>  // HALF: only x0, x1 are produced (last pass: bins >= 512 are never read, MFCC.C:49)
+__device__ __forceinline__ void bfly_pk(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, uint32_t k1a,
+                                        uint32_t k1b, uint32_t k2a, uint32_t k2b, uint32_t k3a, uint32_t k3b)
+{
+    int br, bi, cr, ci, dr, di;
     cxmul(x3, k3a, k3b, dr, di);
     cxmul(x2, k2a, k2b, cr, ci);
     cxmul(x1, k1a, k1b, br, bi);
-    r4_combine<14>(ar, ai, br, bi, cr, ci, dr, di);
-    x0 = pack16(ar, ai);
-    x1 = pack16(br, bi);
-    x2 = pack16(cr, ci);
-    x3 = pack16(di, dr);
+    r4_packed<HALF, true>(x0, br, bi, cr + dr, ci + di, cr - dr, ci - di, x0, x1, x2, x3);
+}
+
+__device__ __forceinline__ void bfly(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, uint32_t k1a, uint32_t k1b,
+                                     uint32_t k2a, uint32_t k2b, uint32_t k3a, uint32_t k3b)
+{
+    bfly_pk<false>(x0, x1, x2, x3, k1a, k1b, k2a, k2b, k3a, k3b);
 }
 
 __device__ __forceinline__ int rev2(int d) { return ((d & 1) << 1) | (d >> 1); }
@@ -218,20 +288,17 @@ __device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const
         uint32_t x2 = y[4 + r2];                                  // d1 = 2 -> rows  64..127
         uint32_t x1 = (d2 == 0) ? y[8] : (d2 == 2) ? y[9] : 0u;   // d1 = 1 -> rows 128..159, else padding
         uint32_t x3 = 0u;                                         // d1 = 3 -> rows >= 192: padding
-        int ar = sext_lo(x0), ai = 0, br = 0, bi = 0, cr, ci, dr = 0, di = 0;
-        // real samples: Y*conj(K) = (Yr*Kc, -Yr*Ks); tw_a = (Kc, Ks) low/high halves
-        cr = mul24(sext_lo(x2), sext_lo(tw.s2[1][0]));
-        ci = -mul24(sext_lo(x2), sext_hi(tw.s2[1][0]));
-        if (d2 == 0 || d2 == 2) {
-            br = mul24(sext_lo(x1), sext_lo(tw.s2[0][0]));
-            bi = -mul24(sext_lo(x1), sext_hi(tw.s2[0][0]));
-        }
+        // real samples: Y*conj(K) = (Yr*Kc, -Yr*Ks); tw_a = (Kc, Ks) low/high halves; D = 0 => C' = D' = C
+        const int cr = mul24(sext_lo(x2), sext_lo(tw.s2[1][0]));
+        const int ci = -mul24(sext_lo(x2), sext_hi(tw.s2[1][0]));
         (void)x3;
-        r4_combine<14>(ar, ai, br, bi, cr, ci, dr, di);
-        v[0][d2] = pack16(ar, ai);
-        v[1][d2] = pack16(br, bi);
-        v[2][d2] = pack16(cr, ci);
-        v[3][d2] = pack16(di, dr);
+        if (d2 == 0 || d2 == 2) {
+            const int br = mul24(sext_lo(x1), sext_lo(tw.s2[0][0]));
+            const int bi = -mul24(sext_lo(x1), sext_hi(tw.s2[0][0]));
+            r4_packed<false, true>(x0, br, bi, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
+        } else {
+            r4_packed<false, false>(x0, 0, 0, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
+        }
     }
 #pragma unroll
     for (int d1 = 0; d1 < 4; d1++)
@@ -386,15 +453,12 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
             wave_sync();
 #pragma unroll
             for (int e3 = 0; e3 < 4; e3++) {
-                int ar = sext_lo(u[e3][0]), ai = sext_hi(u[e3][0]), br, bi, cr, ci, dr, di;
-                cxmul(u[e3][3], tw.s5[e3][2][0], tw.s5[e3][2][1], dr, di);
-                cxmul(u[e3][2], tw.s5[e3][1][0], tw.s5[e3][1][1], cr, ci);
-                cxmul(u[e3][1], tw.s5[e3][0][0], tw.s5[e3][0][1], br, bi);
-                r4_combine<14>(ar, ai, br, bi, cr, ci, dr, di);
-                // ---- |X|*10 and energy (MFCC.C:49-60, 128-133); (s16) = the STRH truncation
+                bfly_pk<true>(u[e3][0], u[e3][1], u[e3][2], u[e3][3], tw.s5[e3][0][0], tw.s5[e3][0][1], tw.s5[e3][1][0],
+                              tw.s5[e3][1][1], tw.s5[e3][2][0], tw.s5[e3][2][1]);
+                // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
-                    const int re = (int)(short)(o ? br : ar), im = (int)(short)(o ? bi : ai);
+                    const int re = sext_lo(u[e3][o]), im = sext_hi(u[e3][o]);
                     const int r = mul24(re, re) + mul24(im, im);
                     const uint32_t mag = (uint32_t)(sqrt_rn_int((float)r) * 10.0f);  // < 2^19
                     buf[lane + 64 * e3 + 256 * o] = umul24(mag, mag);
