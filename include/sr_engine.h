@@ -103,6 +103,12 @@ int sr_set_templates(sr_engine *h, const void *store, uint32_t n_slots, uint32_t
 int sr_set_templates_dense(sr_engine *h, const int16_t *mfcc, const uint32_t *frames, const uint8_t *valid,
                            uint32_t n_templates, uint32_t tpl_stride);
 uint32_t sr_num_templates(const sr_engine *h);
+/* Template training = save_mdl (main.c:121-138): capture i -> noise_atap/VAD/get_mfcc -> slot[i] of the
+ * host store image exactly as save_ftr_mdl programs it (Flash.C:17-67: slot erased to 0xFF, then
+ * save_mask | frm_num | frm_num*12 coefficients).  status[i] (optional): 0 save_ok, 1 VAD_fail,
+ * 2 MFCC_fail (main.c:38-40), 3 SR_ST_SEG_OOB; failed captures leave their slot untouched. */
+int sr_train_store(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t n,
+                   const uint32_t *slot, void *store, uint32_t n_slots, uint32_t stride_bytes, uint32_t *status);
 
 /* ------------------------------------------------------------------ batched recognition
  * B capture buffers of buf_len samples, buffer b at pcm + b*pcm_stride (in samples).
@@ -120,6 +126,15 @@ int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
 int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                            sr_result *d_results, uint32_t *d_scores, int16_t *d_mfcc, sr_vad_rec *d_vad,
                            void *stream);
+
+/* Multi-segment recognition: every segment the VAD returns (up to max_seg, VAD.H:4) is matched like segment 0.
+ * The firmware stops at segment 0 (main.c:268); this is an extension with segment-major outputs:
+ * results[s*B + b], scores[(s*B + b)*K + k]; a segment that does not exist has status SR_ST_VAD_FAIL. */
+int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                                sr_result *results, uint32_t *scores, sr_vad_rec *vad);
+int sr_recognize_segments_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len,
+                                    uint32_t B, sr_result *d_results, uint32_t *d_scores, sr_vad_rec *d_vad,
+                                    void *stream);
 
 /* stage-level entry points on DEVICE buffers (same kernels the full path launches) */
 int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,

@@ -58,8 +58,18 @@ void sr_ref_mfcc(u16 *buf, s32 start, s32 end, atap_tag *atap, v_ftr_tag *ftr)
  * Returns 0 ok, 1 VAD fail (main.c:261-266), 2 MFCC fail (main.c:269-274).
  * scores (optional) receives cur_dis of every slot.
  */
+int sr_ref_spch_recg_seg(u16 *v_dat, u16 buf_len, u16 noise_len, const u8 *store, u32 n_slots, u32 stride,
+                         u32 seg_idx, v_ftr_tag *ftr, u32 *best_slot, u32 *mtch_dis, u32 *scores);
+
 int sr_ref_spch_recg(u16 *v_dat, u16 buf_len, u16 noise_len, const u8 *store, u32 n_slots, u32 stride,
                      v_ftr_tag *ftr, u32 *best_slot, u32 *mtch_dis, u32 *scores)
+{
+    return sr_ref_spch_recg_seg(v_dat, buf_len, noise_len, store, n_slots, stride, 0, ftr, best_slot, mtch_dis, scores);
+}
+
+/* same driver on segment seg_idx of the VAD output (segment 0 = the firmware's behaviour, main.c:268) */
+int sr_ref_spch_recg_seg(u16 *v_dat, u16 buf_len, u16 noise_len, const u8 *store, u32 n_slots, u32 stride,
+                         u32 seg_idx, v_ftr_tag *ftr, u32 *best_slot, u32 *mtch_dis, u32 *scores)
 {
     atap_tag atap;
     valid_tag vv[max_vc_con];
@@ -68,11 +78,11 @@ int sr_ref_spch_recg(u16 *v_dat, u16 buf_len, u16 noise_len, const u8 *store, u3
     *best_slot = 0;
     noise_atap(v_dat, noise_len, &atap);
     VAD(v_dat, buf_len, vv, &atap);
-    if (vv[0].end == (void *)0) {
+    if (vv[seg_idx].end == (void *)0) {
         *mtch_dis = dis_err;
         return 1;
     }
-    get_mfcc(&vv[0], ftr, &atap);
+    get_mfcc(&vv[seg_idx], ftr, &atap);
     if (ftr->frm_num == 0) {
         *mtch_dis = dis_err;
         return 2;

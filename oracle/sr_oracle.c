@@ -414,8 +414,26 @@ uint32_t sr_oracle_dtw(const int16_t *in, uint32_t in_n, const int16_t *mdl, uin
 }
 
 /* ---- main.c:249-296 ----------------------------------------------------- */
+static void recognize_segment(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len, const sr_oracle_templates *tpl,
+                              uint32_t seg_idx, sr_oracle_result *res, int16_t *mfcc_out, uint32_t *scores);
+
 void sr_oracle_recognize(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len, const sr_oracle_templates *tpl,
                          sr_oracle_result *res, int16_t *mfcc_out, uint32_t *scores)
+{
+    recognize_segment(o, pcm, buf_len, tpl, 0, res, mfcc_out, scores);
+}
+
+/* Extension of main.c:249-296 to every segment the VAD returns (the firmware only matches segment 0,
+   main.c:268): res[s], scores[s*n + k] for s < max_seg. */
+void sr_oracle_recognize_segments(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len,
+                                  const sr_oracle_templates *tpl, sr_oracle_result *res, uint32_t *scores)
+{
+    for (uint32_t s = 0; s < o->cfg.max_seg; s++)
+        recognize_segment(o, pcm, buf_len, tpl, s, &res[s], NULL, scores ? scores + (size_t)s * tpl->n : NULL);
+}
+
+static void recognize_segment(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len, const sr_oracle_templates *tpl,
+                              uint32_t seg_idx, sr_oracle_result *res, int16_t *mfcc_out, uint32_t *scores)
 {
     sr_oracle_atap atap;
     int32_t seg[16];
@@ -431,17 +449,17 @@ void sr_oracle_recognize(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_l
         for (uint32_t k = 0; k < tpl->n; k++) scores[k] = SR_ORACLE_DIS_ERR;
     sr_oracle_noise_atap(o, pcm, o->noise_len, &atap);
     sr_oracle_vad(o, pcm, buf_len, &atap, seg);
-    if (seg[1] < 0) {
+    if (seg[2 * seg_idx + 1] < 0) {
         res->status = SR_ORACLE_VAD_FAIL;
         return;
     }
-    if (seg[0] < 1) {
+    if (seg[2 * seg_idx] < 1) {
         res->status = SR_ORACLE_SEG_OOB;
         return;
     }
     if (!mfcc)
-        mfcc = malloc(sizeof(int16_t) * (size_t)(o->cfg.max_frames + 1) * nc);
-    nfrm = sr_oracle_mfcc(o, pcm, seg[0], seg[1], &atap, mfcc);
+        mfcc = calloc((size_t)(o->cfg.max_frames + 1) * nc, sizeof(int16_t));
+    nfrm = sr_oracle_mfcc(o, pcm, seg[2 * seg_idx], seg[2 * seg_idx + 1], &atap, mfcc);
     res->frm_num = nfrm;
     if (nfrm == 0) {
         res->status = SR_ORACLE_MFCC_FAIL;

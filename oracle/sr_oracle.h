@@ -109,6 +109,11 @@ typedef struct sr_oracle_result { /* same record the product writes */
 void sr_oracle_recognize(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len, const sr_oracle_templates *tpl,
                          sr_oracle_result *res, int16_t *mfcc_out, uint32_t *scores);
 
+/* Every VAD segment (up to max_seg) matched like segment 0; extension, the firmware stops at segment 0
+   (main.c:268).  res[max_seg], scores[max_seg * tpl->n] (optional). */
+void sr_oracle_recognize_segments(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len,
+                                  const sr_oracle_templates *tpl, sr_oracle_result *res, uint32_t *scores);
+
 /* B independent buffers (pcm + b*pcm_stride), utterances split over n_threads host threads.
    Used for parity sweeps and for bench.py's cpu_baseline ("port") timing. */
 void sr_oracle_recognize_batch(const sr_oracle *o, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len,

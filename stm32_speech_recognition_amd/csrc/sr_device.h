@@ -67,6 +67,8 @@ struct DtwArgs {
 };
 
 void launch_vad(const VadArgs &a, hipStream_t s);
+void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
+                           hipStream_t s);
 void launch_mfcc(const MfccArgs &a, hipStream_t s);
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 void launch_argmin(const DtwArgs &a, hipStream_t s);

@@ -76,6 +76,7 @@ struct sr_engine {
     DevBuf<sr_result> s_results;
     DevBuf<uint32_t> s_u32a, s_u32b;
     DevBuf<sr_atap> s_atap;
+    DevBuf<sr_vad_rec> s_vad2;
     // profiling: one set of 5 events per profiled call since the last sr_set_profiling(h, 1)
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // 5 per call
@@ -199,6 +200,7 @@ void sr_destroy(sr_engine *h)
     h->s_u32a.release();
     h->s_u32b.release();
     h->s_atap.release();
+    h->s_vad2.release();
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -476,6 +478,46 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
     return SR_OK;
 }
 
+// Every segment the VAD finds (up to max_seg), each matched like segment 0.  The firmware's spch_recg stops at
+// segment 0 (main.c:268); this is the "multi-segment" extension of SURVEY.md 8(f).  Segment-major outputs:
+// d_results[s*B + b], d_scores[(s*B + b)*K + k].
+int sr_recognize_segments_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len,
+                                    uint32_t B, sr_result *d_results, uint32_t *d_scores, sr_vad_rec *d_vad, void *stream)
+{
+    if (!h || !d_results) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if (B == 0) return SR_OK;
+    int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_vad) {
+        if ((rc = h->s_vad.reserve(B))) return rc;
+        d_vad = h->s_vad.p;
+    }
+    if ((rc = h->s_vad2.reserve(B))) return rc;
+    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+    if (!d_scores) {
+        if ((rc = h->s_scores.reserve((size_t)B * h->K * h->cfg.max_seg))) return rc;
+        d_scores = h->s_scores.p;
+    }
+    VadArgs va{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr};
+    launch_vad(va, s);
+    for (uint32_t sg = 0; sg < h->cfg.max_seg; sg++) {
+        launch_select_segment(d_vad, h->s_vad2.p, B, sg, h->cfg.max_frames, s);
+        launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, h->s_vad2.p, h->s_mfcc.p), s);
+        DtwArgs da = dtw_args(h, h->s_mfcc.p, h->s_vad2.p, nullptr, B, d_scores + (size_t)sg * B * h->K,
+                              d_results + (size_t)sg * B);
+        launch_dtw(da, s);
+        launch_argmin(da, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                                sr_result *results, uint32_t *scores, sr_vad_rec *vad);
+
 // ---- host-buffer wrappers (stage through HBM) --------------------------------------------------------
 static int stage_pcm(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                      uint64_t *dev_stride)
@@ -510,6 +552,29 @@ int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
     if (scores) HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
     if (mfcc)
         HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * kCoef * 2, hipMemcpyDeviceToHost));
+    if (vad) HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                                sr_result *results, uint32_t *scores, sr_vad_rec *vad)
+{
+    if (!h || !pcm || !results) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if (B == 0) return SR_OK;
+    if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t ms = h->cfg.max_seg;
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_results.reserve((size_t)B * ms))) return rc;
+    if ((rc = h->s_vad.reserve(B))) return rc;
+    if ((rc = h->s_scores.reserve((size_t)B * h->K * ms))) return rc;
+    rc = sr_recognize_segments_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_results.p, h->s_scores.p, h->s_vad.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(results, h->s_results.p, (size_t)B * ms * sizeof(sr_result), hipMemcpyDeviceToHost));
+    if (scores) HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * ms * 4, hipMemcpyDeviceToHost));
     if (vad) HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
     return SR_OK;
 }
@@ -582,6 +647,48 @@ int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32
     HIP_TRY(hipMemcpy(h->s_vad.p, recs.data(), (size_t)B * sizeof(sr_vad_rec), hipMemcpyHostToDevice));
     if ((rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, B, h->s_vad.p, h->s_mfcc.p, nullptr))) return rc;
     HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * kCoef * 2, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// Template training: save_mdl (main.c:121-138) for n captures + the slot image save_ftr_mdl programs
+// (Flash.C:17-67): on success the slot is erased (0xFF) and u16 save_mask | u16 frm_num | frm_num*12 s16 are
+// written; on VAD / MFCC failure the slot is left untouched (main.c:126-135).
+int sr_train_store(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t n,
+                   const uint32_t *slot, void *store, uint32_t n_slots, uint32_t stride_bytes, uint32_t *status)
+{
+    if (!h || !pcm || !slot || !store) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (n == 0) return SR_OK;
+    if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    if (stride_bytes < 4 + 2 * kCoef) return fail(SR_ERR_BAD_ARG, "slot stride too small for a v_ftr_tag");
+    const uint32_t slot_rows = (stride_bytes - 4) / (2 * kCoef);
+    for (uint32_t i = 0; i < n; i++)
+        if (slot[i] >= n_slots) return fail(SR_ERR_BAD_ARG, "slot index outside the store");  // Flash.C:22-26
+    HIP_TRY(hipSetDevice(h->device));
+    uint64_t ds = 0;
+    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, n, &ds);
+    if (rc) return rc;
+    if ((rc = h->s_vad.reserve(n))) return rc;
+    const size_t msz = (size_t)n * h->cfg.max_frames * kCoef;
+    if ((rc = h->s_mfcc.reserve(msz))) return rc;
+    if ((rc = sr_vad_batch_dev(h, h->s_pcm.p, ds, buf_len, n, h->s_vad.p, nullptr))) return rc;
+    if ((rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, n, h->s_vad.p, h->s_mfcc.p, nullptr))) return rc;
+    std::vector<sr_vad_rec> recs(n);
+    std::vector<int16_t> mf(msz);
+    HIP_TRY(hipMemcpy(recs.data(), h->s_vad.p, (size_t)n * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mf.data(), h->s_mfcc.p, msz * 2, hipMemcpyDeviceToHost));
+    uint8_t *st = (uint8_t *)store;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t code = recs[i].status;  // 0 save_ok, 1 VAD_fail, 2 MFCC_fail (main.c:38-40)
+        if (code == SR_ST_OK && recs[i].frm_num > slot_rows) code = SR_ST_MFCC_FAIL;
+        if (status) status[i] = code;
+        if (code != SR_ST_OK) continue;
+        uint8_t *dst = st + (size_t)slot[i] * stride_bytes;
+        std::memset(dst, 0xFF, stride_bytes);  // FLASH_ErasePage, Flash.C:32-39
+        const uint16_t sign = SR_SAVE_MASK, fr = (uint16_t)recs[i].frm_num;
+        std::memcpy(dst, &sign, 2);
+        std::memcpy(dst + 2, &fr, 2);
+        std::memcpy(dst + 4, &mf[(size_t)i * h->cfg.max_frames * kCoef], (size_t)fr * kCoef * 2);
+    }
     return SR_OK;
 }
 

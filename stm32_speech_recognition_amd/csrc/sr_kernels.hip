@@ -840,6 +840,35 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
     }
 }
 
+// Re-targets the per-utterance records at VAD segment `seg_idx` (0..2): the frame and DTW kernels always work
+// on "segment 0" of the record they are given.  Frame count and status follow MFCC.C:102-107 / main.c:261-274.
+__global__ void k_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    sr_vad_rec r = in[b];
+    const int st = r.seg[2 * seg_idx], en = r.seg[2 * seg_idx + 1];
+    r.seg[0] = st;
+    r.seg[1] = en;
+    r.frm_num = 0;
+    if (en < 0) {
+        r.status = SR_ST_VAD_FAIL;
+    } else if (st < 1) {
+        r.status = SR_ST_SEG_OOB;
+    } else {
+        const uint32_t n = ((((uint32_t)(en - st) - kFrameLen) / kHop) + 1) & 0xFFFF;
+        r.status = n > max_frames ? SR_ST_MFCC_FAIL : SR_ST_OK;
+        r.frm_num = n > max_frames ? 0 : n;
+    }
+    out[b] = r;
+}
+void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
+                           hipStream_t s)
+{
+    if (!B) return;
+    hipLaunchKernelGGL(k_select_segment, dim3((B + 255) / 256), dim3(256), 0, s, in, out, B, seg_idx, max_frames);
+}
+
 void launch_vad(const VadArgs &a, hipStream_t s)
 {
     if (!a.B) return;

@@ -115,6 +115,19 @@ class Engine:
         store = np.ascontiguousarray(store, dtype=np.uint8)
         self._check(self.L.sr_set_templates(self.h, _vp(store), C.c_uint32(len(store) // stride), C.c_uint32(stride)))
 
+    def train_store(self, pcm, slots, store=None, n_slots=80, stride=4096):
+        """save_mdl for each row of pcm into slot slots[i] of a flash-style store image (created erased,
+        all 0xFF, when not given).  Returns (store uint8 [n_slots*stride], status uint32 [n])."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        n, S = pcm.shape
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        if store is None:
+            store = np.full(n_slots * stride, 0xFF, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.uint32)
+        self._check(self.L.sr_train_store(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(n), _vp(slots),
+                                          _vp(store), C.c_uint32(len(store) // stride), C.c_uint32(stride), _vp(status)))
+        return store, status
+
     # ---- host-buffer API --------------------------------------------------------------------------
     def recognize(self, pcm, want_scores=True, want_mfcc=True, want_vad=True, buf_len=None):
         """pcm uint16 [B, S] on the host.  Returns dict(results, scores, mfcc, vad) of numpy arrays."""
@@ -129,6 +142,18 @@ class Engine:
         self._check(self.L.sr_recognize_batch(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(buf_len), C.c_uint32(B),
                                               _vp(res), _vp(sc), _vp(mf), _vp(vd)))
         return dict(results=res, scores=sc, mfcc=mf, vad=vd)
+
+    def recognize_segments(self, pcm):
+        """All VAD segments (extension of main.c:268).  Returns (results [max_seg, B], scores [max_seg, B, K], vad [B])."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        B, S = pcm.shape
+        ms, K = self.cfg.max_seg, self.n_templates
+        res = np.zeros((ms, B), dtype=RESULT_DTYPE)
+        sc = np.zeros((ms, B, K), dtype=np.uint32)
+        vd = np.zeros(B, dtype=VAD_DTYPE)
+        self._check(self.L.sr_recognize_segments_batch(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B),
+                                                       _vp(res), _vp(sc), _vp(vd)))
+        return res, sc, vd
 
     def vad(self, pcm, buf_len=None):
         pcm = np.ascontiguousarray(pcm, dtype=np.uint16)

@@ -103,6 +103,24 @@ def make_utterances(word_ids, frames, seed, bank, S=None, gain=1.0, head_sigma=8
     return out
 
 
+def make_multiword(word_ids, frames, seed, bank, S=16000, gap=1200, **kw):
+    """One capture buffer holding several words separated by `gap` quiet samples (>= 11 quiet frames so the
+    VAD closes each segment, VAD.C:198-206).  Returns an int16 tensor [S] of ADC codes."""
+    g = torch.Generator().manual_seed(seed)
+    out = (MID + 4.0 * torch.randn(S, generator=g)).round().clamp(0, 4095).to(torch.int16)
+    out[:NOISE_LEN] = (MID + 8.0 * torch.randn(NOISE_LEN, generator=g)).round().clamp(0, 4095).to(torch.int16)
+    pos = NOISE_LEN + LEAD_QUIET + HOP
+    for i, (w, t) in enumerate(zip(word_ids, frames)):
+        one = make_utterances([w], [t], seed=seed * 31 + i, bank=bank, S=buf_len_for(t), **kw)[0]
+        p0 = NOISE_LEN + LEAD_QUIET + HOP
+        span = HOP * (t - 1)
+        if pos + span + gap > S:
+            break
+        out[pos:pos + span] = one[p0:p0 + span]
+        pos += span + gap
+    return out
+
+
 def as_u16_numpy(x):
     """int16 torch tensor of ADC codes -> numpy uint16 (same bits)."""
     import numpy as np

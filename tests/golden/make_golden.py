@@ -124,10 +124,36 @@ def main():
         dd[p] = r.dtw(ol.RefLib.make_ftr(a, na), ol.RefLib.make_ftr(bb, nb))
     g["dtw_len"], g["dtw_a"], g["dtw_b"], g["dtw_dis"] = dl, da, db, dd
 
+    # --- multi-word captures: every VAD segment through the reference objects (get_mfcc + dtw per segment).
+    #     Appended last so the random stream of the sections above stays as it was.
+    M = 6
+    mw = np.zeros((M, 16000), dtype=np.uint16)
+    plans = [([1, 4, 7], [30, 40, 25]), ([2, 2], [60, 50]), ([9], [100]), ([0, 3, 5], [20, 20, 20]),
+             ([6, 8, 1], [45, 30, 35]), ([3, 3, 3], [28, 33, 38])]
+    for i, (w, t) in enumerate(plans):
+        mw[i] = synth.as_u16_numpy(synth.make_multiword(w, t, seed=900 + i, bank=bank))
+    mseg = np.zeros((M, 6), dtype=np.int32)
+    mst = np.zeros((M, 3), dtype=np.uint32)
+    mbest = np.zeros((M, 3), dtype=np.uint32)
+    mdis = np.zeros((M, 3), dtype=np.uint32)
+    msc = np.zeros((M, 3, K), dtype=np.uint32)
+    mfr = np.zeros((M, 3), dtype=np.uint32)
+    for i in range(M):
+        a, sg = r.vad(mw[i])
+        mseg[i] = sg
+        for s_ in range(3):
+            mst[i, s_], mbest[i, s_], mdis[i, s_], msc[i, s_], _, mfr[i, s_] = r.spch_recg(mw[i], store, seg_idx=s_)
+            if mst[i, s_] != 0:
+                msc[i, s_] = 0xFFFFFFFF
+                mfr[i, s_] = 0
+    g["multi_pcm"], g["multi_seg"], g["multi_status"], g["multi_best"] = mw, mseg, mst, mbest
+    g["multi_dis"], g["multi_scores"], g["multi_frm"] = mdis, msc, mfr
+
     out = os.path.join(HERE, "ref_golden.npz")
     np.savez_compressed(out, **g)
     print("wrote", out, os.path.getsize(out), "bytes;",
-          "status", st.tolist(), "frm", nfrm.tolist(), "dtw err", int((dd == 0xFFFFFFFF).sum()))
+          "status", st.tolist(), "frm", nfrm.tolist(), "dtw err", int((dd == 0xFFFFFFFF).sum()),
+          "multi status", mst.tolist(), "multi frm", mfr.tolist())
 
 
 if __name__ == "__main__":

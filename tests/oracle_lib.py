@@ -168,6 +168,19 @@ class Oracle:
         return res, mf, sc
 
 
+def _oracle_recognize_segments(self, pcm, tpl):
+    """pcm uint16 [S] -> (results[max_seg], scores[max_seg, K])"""
+    pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+    ms = self.cfg.max_seg
+    res = np.zeros(ms, dtype=RESULT_DTYPE)
+    sc = np.zeros((ms, tpl.n), dtype=np.uint32)
+    self.L.sr_oracle_recognize_segments(self.h, _p(pcm), C.c_uint32(len(pcm)), C.byref(tpl), _p(res), _p(sc))
+    return res, sc
+
+
+Oracle.recognize_segments = _oracle_recognize_segments
+
+
 class RefLib:
     """Tier (i): the reference's own objects.  Non-reentrant (file-scope statics): single thread only."""
     FTR_BYTES = 2860  # sizeof(v_ftr_tag) at vv_frm_max = 119 (MFCC.H:18-25)
@@ -220,7 +233,7 @@ class RefLib:
     def dtw(self, ftr_in, ftr_mdl):
         return self.L.dtw(_p(ftr_in), _p(ftr_mdl))
 
-    def spch_recg(self, pcm, store, stride=4096, noise_len=2400):
+    def spch_recg(self, pcm, store, stride=4096, noise_len=2400, seg_idx=0):
         """store: uint8 [n_slots*stride] flash-style image.  Returns (status, best_slot, dis, scores, mfcc, n)."""
         pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
         n_slots = len(store) // stride
@@ -228,8 +241,8 @@ class RefLib:
         best = C.c_uint32(0)
         dis = C.c_uint32(0)
         scores = np.zeros(n_slots, dtype=np.uint32)
-        st = self.L.sr_ref_spch_recg(_p(pcm), C.c_uint16(len(pcm)), C.c_uint16(noise_len), _p(store),
-                                     C.c_uint32(n_slots), C.c_uint32(stride), _p(ftr), C.byref(best), C.byref(dis),
-                                     _p(scores))
+        st = self.L.sr_ref_spch_recg_seg(_p(pcm), C.c_uint16(len(pcm)), C.c_uint16(noise_len), _p(store),
+                                         C.c_uint32(n_slots), C.c_uint32(stride), C.c_uint32(seg_idx), _p(ftr),
+                                         C.byref(best), C.byref(dis), _p(scores))
         n = int(ftr.view(np.uint16)[1])
         return st, best.value, dis.value, scores, ftr.view(np.int16)[2:2 + n * 12].reshape(n, 12).copy(), n

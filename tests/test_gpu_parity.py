@@ -261,3 +261,39 @@ def test_compat_symbols_match_golden(golden, oracle):
         assert label is not None and label[:1] == str(idx).encode()
     label, dis = compat.spch_recg(np.full(16000, 2048, np.uint16))
     assert label is None and dis == compat.DIS_ERR  # main.c:261-266
+
+
+# ----------------------------------------------------------------------------- SURVEY 8(f) rows
+def test_recognize_segments_matches_golden(eng119, golden):
+    """multi-segment recognition against the reference objects' per-segment get_mfcc + dtw"""
+    eng119.set_templates_store(golden["store"])
+    res, sc, vd = eng119.recognize_segments(golden["multi_pcm"])
+    assert np.array_equal(vd["seg"], golden["multi_seg"])
+    for s_ in range(3):
+        assert np.array_equal(res[s_]["status"], golden["multi_status"][:, s_]), s_
+        assert np.array_equal(res[s_]["frm_num"], golden["multi_frm"][:, s_])
+        assert np.array_equal(res[s_]["min_dis"], golden["multi_dis"][:, s_])
+        assert np.array_equal(res[s_]["best_tpl"], golden["multi_best"][:, s_])
+        assert np.array_equal(sc[s_], golden["multi_scores"][:, s_])
+
+
+def test_train_store_matches_reference_layout(golden):
+    """save_mdl for a batch of captures -> flash image (Flash.C:17-67), then recognise with that image"""
+    from stm32_speech_recognition_amd import Engine
+    from test_oracle import expected_store_image
+    e = Engine(max_frames=119, device=0)
+    pcm = golden["pcm"]
+    B = pcm.shape[0]
+    pcm2 = np.concatenate([pcm, np.full((1, pcm.shape[1]), 2048, np.uint16)])  # + one silent capture: VAD_fail
+    slots = np.array([3 * i for i in range(B)] + [79], np.uint32)
+    store, status = e.train_store(pcm2, slots)
+    assert status[B] == 1 and (status[:B] == 0).all()
+    want = expected_store_image([golden["mfcc"][b] for b in range(B)] + [None], list(golden["frm_num"]) + [0], slots,
+                                status=status)
+    assert np.array_equal(store, want)
+    assert (store[79 * 4096:80 * 4096] == 0xFF).all()  # failed capture leaves its slot untouched
+    # the trained image is a valid template store: every training capture matches itself with distance 0
+    e.set_templates_store(store)
+    out = e.recognize(pcm)
+    assert np.array_equal(out["results"]["best_tpl"], slots[:B]) and (out["results"]["min_dis"] == 0).all()
+    e.close()

@@ -259,3 +259,50 @@ def test_reference_adc_dump_probe_values(oracle):
     r = ol.RefLib()
     a1, s1 = r.vad(vals)
     assert a1.astuple() == a.astuple() and np.array_equal(s1, seg)
+
+
+# ----------------------------------------------------------------------------- SURVEY 8(f) rows
+def test_recognize_segments_matches_golden(oracle, golden):
+    """every VAD segment matched like segment 0 (extension of main.c:268); fixture from the reference objects"""
+    tm, tf, tv = store_to_templates(golden["store"])
+    tpl = oracle.make_templates(tm, tf, tv)
+    mw = golden["multi_pcm"]
+    for i in range(mw.shape[0]):
+        res, sc = oracle.recognize_segments(mw[i], tpl)
+        assert np.array_equal(res["status"], golden["multi_status"][i])
+        assert np.array_equal(res["frm_num"], golden["multi_frm"][i])
+        assert np.array_equal(res["min_dis"], golden["multi_dis"][i])
+        assert np.array_equal(res["best_tpl"], golden["multi_best"][i])
+        assert np.array_equal(sc, golden["multi_scores"][i])
+    assert (golden["multi_status"] == 0).sum() >= 12 and (golden["multi_status"] == 1).sum() >= 2
+
+
+def expected_store_image(mfcc_rows, frames, slots, n_slots=80, stride=4096, status=None):
+    """what save_ftr_mdl leaves in flash (Flash.C:17-67): erased 0xFF slot, then save_mask | frm_num | rows"""
+    store = np.full(n_slots * stride, 0xFF, dtype=np.uint8)
+    for i, sl in enumerate(slots):
+        if status is not None and status[i] != 0:
+            continue
+        n = int(frames[i])
+        img = np.full(stride, 0xFF, dtype=np.uint8)
+        img[:4].view(np.uint16)[:] = (12345, n)
+        img[4:4 + n * 24] = np.ascontiguousarray(mfcc_rows[i][:n], dtype=np.int16).view(np.uint8).reshape(-1)
+        store[sl * stride:(sl + 1) * stride] = img
+    return store
+
+
+def test_store_image_round_trip(oracle, golden):
+    """flash-layout image built from MFCC rows parses back to the dense template layout"""
+    pcm = golden["pcm"][:6]
+    rows, frames = [], []
+    for b in range(6):
+        n = int(golden["frm_num"][b])
+        rows.append(golden["mfcc"][b, :n])
+        frames.append(n)
+    slots = [0, 5, 17, 42, 60, 79]
+    img = expected_store_image(rows, frames, slots)
+    tm, tf, tv = store_to_templates(img)
+    assert tv.sum() == 6 and [int(tf[s]) for s in slots] == frames
+    for s_, r in zip(slots, rows):
+        assert np.array_equal(tm[s_, :len(r)], r)
+    assert (tm[1, :119] == -1).all() and tv[1] == 0  # erased slot: 0xFFFF halves, not valid
