@@ -1,0 +1,70 @@
+"""Turn rocprofv3 CSV output (kernel stats + separate --pmc passes) into the committed summaries.
+
+  python profiles/summarize.py <gpurun_out/profdir> <tag>   ->  profiles/<tag>_rocprof_summary.csv
+                                                                profiles/pmc_traffic.json  (read by bench.py)
+profdir layout: stats/*kernel_stats.csv and pmc_<COUNTER>/*counter_collection.csv (one dir per --pmc pass).
+Only the engine's own kernels (sr::*) are kept; torch's data-generation kernels are dropped.
+HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE
+reports half of a coalesced stream, hence hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = [f"# rocprofv3 summary {tag}: python bench.py --steps 5 --warmup 1 --no-cpu-baseline on 1x MI355X (B=65536, K=100, T=256)",
+           "# rocprofv3 --kernel-trace --stats --output-format csv   (first k_vad/k_mfcc launch = the 100-utterance template pass)",
+           "kernel,calls,avg_ns,min_ns,max_ns,pct"]
+    for f in glob.glob(os.path.join(root, "stats", "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Name"].startswith("sr::"):
+                out.append(f"{r['Name']},{r['Calls']},{r['AverageNs']},{r['MinNs']},{r['MaxNs']},{r['Percentage']}")
+    out += ["", "# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <counters>), LAST full-batch launch",
+            "kernel,counter,value"]
+    vals = {}
+    for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+        fs = glob.glob(os.path.join(d, "*counter_collection.csv"))
+        if not fs:
+            continue
+        acc = collections.defaultdict(dict)
+        for r in csv.DictReader(open(fs[0])):
+            if r["Kernel_Name"].startswith("sr::"):
+                acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] = float(r["Counter_Value"])
+        for k in acc:
+            for c, v in sorted(acc[k].items()):
+                out.append(f"{k},{c},{v:.0f}")
+                vals[(k, c)] = v
+    # derived: VALU issue utilisation = SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) * 4 / (SIMDs * kernel cycles)
+    out += ["", "# derived (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs)", "kernel,metric,value"]
+    for k in ("sr::k_mfcc", "sr::k_dtw_lds", "sr::k_vad"):
+        try:
+            cyc = vals[(k, "GRBM_GUI_ACTIVE")] / 8.0
+            busy = vals[(k, "SQ_ACTIVE_INST_VALU")] * 4.0 / (1024.0 * cyc)
+            out.append(f"{k},valu_busy_fraction,{busy:.3f}")
+            out.append(f"{k},cycles_per_valu_inst,{vals[(k, 'SQ_ACTIVE_INST_VALU')] * 4.0 / vals[(k, 'SQ_INSTS_VALU')]:.2f}")
+            if (k, "SQ_LDS_IDX_ACTIVE") in vals:
+                out.append(f"{k},lds_busy_fraction,{vals[(k, 'SQ_LDS_IDX_ACTIVE')] / (256.0 * cyc):.3f}")
+                out.append(f"{k},lds_conflict_fraction,{vals[(k, 'SQ_LDS_BANK_CONFLICT')] / max(1.0, vals[(k, 'SQ_LDS_IDX_ACTIVE')]):.3f}")
+        except KeyError:
+            pass
+    if ("sr::k_mfcc", "SQ_INSTS_VALU") in vals:
+        out.append(f"sr::k_mfcc,valu_insts_per_frame,{vals[('sr::k_mfcc', 'SQ_INSTS_VALU')] / (65536 * 256.0):.1f}")
+    open(os.path.join(here, f"{tag}_rocprof_summary.csv"), "w").write("\n".join(out) + "\n")
+    if ("sr::k_mfcc", "FETCH_SIZE") in vals:
+        fs_, ws = vals[("sr::k_mfcc", "FETCH_SIZE")], vals[("sr::k_mfcc", "WRITE_SIZE")]
+        j = {"source": f"profiles/{tag}_rocprof_summary.csv", "kernel": "sr::k_mfcc", "B": 65536,
+             "FETCH_SIZE_KB": fs_, "WRITE_SIZE_KB": ws,
+             "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM section)",
+             "k_mfcc_hbm_bytes_per_launch": int((2 * fs_ + ws) * 1024)}
+        json.dump(j, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
+    print("\n".join(out[-14:]))
+
+
+if __name__ == "__main__":
+    main()
