@@ -269,11 +269,33 @@ __device__ __forceinline__ void load_lane_tw(const DevTables &t, int lane, LaneT
     for (int d3 = 0; d3 < 4; d3++) load_tw3(t, 252, lane + 64 * d3, tw.s5[d3]);
 }
 
+// 24 lane-invariant coefficient words parked in LDS as 6 x 16-byte chunks, chunk c of lane l at [c*64 + l]
+// (consecutive lanes -> consecutive 16-byte slots: conflict-free ds_read_b128 / ds_write_b128)
+__device__ __forceinline__ void store_tw24(u32x4 *lds, int lane, const uint32_t (&k)[4][3][2])
+{
+    const uint32_t *f = &k[0][0][0];
+#pragma unroll
+    for (int c = 0; c < 6; c++) lds[c * 64 + lane] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+}
+__device__ __forceinline__ void load_tw24(const u32x4 *lds, int lane, uint32_t (&k)[4][3][2])
+{
+    uint32_t *f = &k[0][0][0];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const u32x4 q = lds[c * 64 + lane];
+        f[4 * c] = q.x;
+        f[4 * c + 1] = q.y;
+        f[4 * c + 2] = q.z;
+        f[4 * c + 3] = q.w;
+    }
+}
+
 // Passes 1-3 for the zero-padded real frame that get_mfcc feeds (MFCC.C:37-47): only x[0..159] are
 // non-zero and every imaginary part is 0.  Pass 1 (.s:226-232) then degenerates exactly to
 // out[4*idx+k] = x[bitrev8(idx)] >> 2 (k = 0..3), so it is folded into the gather.
 // lane = d0 + 4*d3 + 16*d4 ; v[d1][d2] <-> j = d0 + 4*d1 + 16*d2 + 64*d3 + 256*d4.
-__device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const LaneTw &tw, uint32_t (&v)[4][4])
+__device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const LaneTw &tw, const u32x4 *tw3_lds,
+                                                  uint32_t (&v)[4][4])
 {
     const int d3 = (lane >> 2) & 3, d4 = lane >> 4;
     const int base = rev2(d4) + 4 * rev2(d3);
@@ -300,10 +322,13 @@ __device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const
             r4_packed<false, false>(x0, 0, 0, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
         }
     }
+    // pass-3 coefficients (24 words per lane) are parked in LDS, shared by the workgroup's waves
+    uint32_t k3[4][3][2];
+    load_tw24(tw3_lds, lane, k3);
 #pragma unroll
     for (int d1 = 0; d1 < 4; d1++)
-        bfly(v[d1][0], v[d1][1], v[d1][2], v[d1][3], tw.s3[d1][0][0], tw.s3[d1][0][1], tw.s3[d1][1][0],
-             tw.s3[d1][1][1], tw.s3[d1][2][0], tw.s3[d1][2][1]);
+        bfly(v[d1][0], v[d1][1], v[d1][2], v[d1][3], k3[d1][0][0], k3[d1][0][1], k3[d1][1][0], k3[d1][1][1],
+             k3[d1][2][0], k3[d1][2][1]);
 }
 
 // lane (d0,d3,d4) -> LDS -> lane' = j & 63 holding u[d3][d4]
@@ -347,10 +372,11 @@ __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__res
     return (uint32_t)m;
 }
 
-__global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
+__global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ int8_t s_dct[kCoef * kMel];
+    __shared__ u32x4 s_tw3[6 * 64], s_tw5[6 * 64];  // pass-3 / pass-5 coefficients of every lane (same for all waves)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
     int *xw = (int *)(buf + kXchgWords);
@@ -362,6 +388,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
     // ---- lane-invariant constants --------------------------------------------------------------
     LaneTw tw;
     load_lane_tw(a.t, lane, tw);
+    if (w == 0) store_tw24(s_tw3, lane, tw.s3);
+    if (w == 1 % kMfccWaves) store_tw24(s_tw5, lane, tw.s5);
+    __syncthreads();
     int hamm_r[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
@@ -443,7 +472,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
             wave_sync();
             // ---- FFT passes 1-3 in registers, exchange, passes 4-5 in registers
             uint32_t v[4][4], u[4][4];
-            fft_front_real160(xw, lane, tw, v);
+            fft_front_real160(xw, lane, tw, s_tw3, v);
             fft_exchange(buf, lane, v, u);
 #pragma unroll
             for (int e4 = 0; e4 < 4; e4++)
@@ -451,10 +480,12 @@ __global__ void __launch_bounds__(64 * kMfccWaves) k_mfcc(const MfccArgs a)
                      tw.s4[2][0], tw.s4[2][1]);
             // pass 5: only x[j] and x[j+q] (bins < 512) are consumed (MFCC.C:49)
             wave_sync();
+            uint32_t k5[4][3][2];
+            load_tw24(s_tw5, lane, k5);
 #pragma unroll
             for (int e3 = 0; e3 < 4; e3++) {
-                bfly_pk<true>(u[e3][0], u[e3][1], u[e3][2], u[e3][3], tw.s5[e3][0][0], tw.s5[e3][0][1], tw.s5[e3][1][0],
-                              tw.s5[e3][1][1], tw.s5[e3][2][0], tw.s5[e3][2][1]);
+                bfly_pk<true>(u[e3][0], u[e3][1], u[e3][2], u[e3][3], k5[e3][0][0], k5[e3][0][1], k5[e3][1][0],
+                              k5[e3][1][1], k5[e3][2][0], k5[e3][2][1]);
                 // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
