@@ -153,6 +153,14 @@ int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32
 /* all-pairs greedy DTW of B feature sequences (in_mfcc[b*max_frames*n_coef], in_frames[b]) against the store */
 int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores,
                  sr_result *results);
+/* OPT-IN, NON-REFERENCE scorer: full dynamic-programming DTW (anti-diagonal wavefront across the 64-lane wave,
+ * template staged in LDS) with the reference's parallelogram (dtw_limit) and local distance (get_dis):
+ *   D(1,1)=d(1,1); D(x,y)=d(x,y)+min(D(x-1,y-1),D(x-1,y),D(x,y-1)); score = D(in,mdl)/(in+mdl), dis_err if gated/unreachable.
+ * The reference's dtw() is a greedy walk (DTW.C:150-188), so these scores differ from dtw()'s by design and are
+ * never used by sr_recognize_* or the dtw symbol. */
+int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores);
+int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_in_frames, const sr_vad_rec *d_vad,
+                        uint32_t B, uint32_t *d_scores, void *stream);
 /* generic 1024-point Q15 FFT of n independent packed-complex arrays (re = low half, im = high half) */
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
 

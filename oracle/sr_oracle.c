@@ -413,6 +413,49 @@ uint32_t sr_oracle_dtw(const int16_t *in, uint32_t in_n, const int16_t *mdl, uin
     return dis / step;
 }
 
+/* ---- NON-REFERENCE extension: full dynamic-programming DTW ---------------
+ * Own definition (no reference counterpart; the reference's dtw() is the greedy walk above):
+ *   cells (x,y), 1-based, allowed iff dtw_limit(x,y) == ins (DTW.C:76-109) with the pair's X1/X2;
+ *   d = get_dis (DTW.C:45-62); D(1,1) = d(1,1); D(x,y) = d(x,y) + min over allowed, reachable
+ *   predecessors (x-1,y-1), (x-1,y), (x,y-1); sums saturate at 0xFFFFFFFE;
+ *   result = D(in,mdl) / (in+mdl), dis_err when the length gate (DTW.C:133) fails or the end cell is unreachable. */
+uint32_t sr_oracle_dtw_dp(const int16_t *in, uint32_t in_n, const int16_t *mdl, uint32_t mdl_n, uint32_t nc)
+{
+    const uint32_t INF = 0xFFFFFFFFu;
+    uint32_t *prev, *cur, res;
+    int X1, X2;
+    if (!in_n || !mdl_n || in_n > mdl_n * 2 || 2 * in_n < mdl_n)
+        return SR_ORACLE_DIS_ERR;
+    X1 = (int)(uint16_t)((2 * (int)mdl_n - (int)in_n) / 3);
+    X2 = (int)(uint16_t)((4 * (int)in_n - 2 * (int)mdl_n) / 3);
+    prev = malloc(sizeof(uint32_t) * (mdl_n + 1));
+    cur = malloc(sizeof(uint32_t) * (mdl_n + 1));
+    for (uint32_t y = 0; y <= mdl_n; y++) prev[y] = INF;
+    for (uint32_t x = 1; x <= in_n; x++) { /* column by column; prev = column x-1 */
+        cur[0] = INF;
+        for (uint32_t y = 1; y <= mdl_n; y++) {
+            uint32_t best, d, sum;
+            cur[y] = INF;
+            if (dtw_outside((int)x, (int)y, X1, X2, (int)in_n, (int)mdl_n))
+                continue;
+            best = prev[y - 1];
+            if (prev[y] < best) best = prev[y];
+            if (cur[y - 1] < best) best = cur[y - 1];
+            if (x == 1 && y == 1) best = 0;
+            if (best == INF)
+                continue;
+            d = sr_oracle_get_dis(in + (size_t)(x - 1) * nc, mdl + (size_t)(y - 1) * nc, nc);
+            sum = best + d;
+            cur[y] = (sum < best || sum == INF) ? 0xFFFFFFFEu : sum;
+        }
+        { uint32_t *t = prev; prev = cur; cur = t; }
+    }
+    res = prev[mdl_n] == INF ? SR_ORACLE_DIS_ERR : prev[mdl_n] / (in_n + mdl_n);
+    free(prev);
+    free(cur);
+    return res;
+}
+
 /* ---- main.c:249-296 ----------------------------------------------------- */
 static void recognize_segment(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len, const sr_oracle_templates *tpl,
                               uint32_t seg_idx, sr_oracle_result *res, int16_t *mfcc_out, uint32_t *scores);

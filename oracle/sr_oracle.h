@@ -85,6 +85,10 @@ uint32_t sr_oracle_get_dis(const int16_t *a, const int16_t *b, uint32_t n_coef);
 uint32_t sr_oracle_dtw(const int16_t *in, uint32_t in_frames, const int16_t *mdl, uint32_t mdl_frames,
                        uint32_t n_coef);
 
+/* NON-REFERENCE extension (own definition, see sr_oracle.c): full-DP DTW with the same parallelogram and distance. */
+uint32_t sr_oracle_dtw_dp(const int16_t *in, uint32_t in_frames, const int16_t *mdl, uint32_t mdl_frames,
+                          uint32_t n_coef);
+
 /*
  * Template store in the batched layout: tpl_mfcc[k] starts at k*tpl_stride int16s,
  * frame-major; tpl_frames[k] = frm_num; tpl_valid[k] != 0 <=> save_sign == 12345.

@@ -72,6 +72,7 @@ void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, ui
 void launch_mfcc(const MfccArgs &a, hipStream_t s);
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
+void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer
 // generic complex 1024-point Q15 FFT, n arrays (cr4_fft_1024_stm32 semantics)
 void launch_fft_q15(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
 // magnitude*10 of bins 0..511 of zero-padded real frames: fft() of MFCC.C:27-62.

@@ -718,6 +718,41 @@ int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames
     return SR_OK;
 }
 
+// OPT-IN, NON-REFERENCE: full dynamic-programming DTW with the reference's parallelogram and local distance
+// (see k_dtw_dp).  Never used by sr_recognize_* or the dtw() symbol.
+int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_in_frames, const sr_vad_rec *d_vad,
+                        uint32_t B, uint32_t *d_scores, void *stream)
+{
+    if (!h || !d_mfcc || !d_scores || (!d_in_frames && !d_vad)) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if ((size_t)h->tpl_rows * 48 > 150 * 1024) return fail(SR_ERR_BAD_ARG, "templates too long for the LDS-staged DP kernel");
+    HIP_TRY(hipSetDevice(h->device));
+    DtwArgs a = dtw_args(h, d_mfcc, d_vad, d_in_frames, B, d_scores, nullptr);
+    launch_dtw_dp(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores)
+{
+    if (!h || !in_mfcc || !in_frames || !scores) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if (B == 0) return SR_OK;
+    for (uint32_t b = 0; b < B; b++)
+        if (in_frames[b] > h->cfg.max_frames) return fail(SR_ERR_BAD_ARG, "in_frames exceeds max_frames");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
+    if ((rc = h->s_mfcc.reserve(msz))) return rc;
+    if ((rc = h->s_u32a.reserve(B))) return rc;
+    if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
+    HIP_TRY(hipMemcpy(h->s_mfcc.p, in_mfcc, msz * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->s_u32a.p, in_frames, (size_t)B * 4, hipMemcpyHostToDevice));
+    if ((rc = sr_dtw_dp_batch_dev(h, h->s_mfcc.p, h->s_u32a.p, nullptr, B, h->s_scores.p, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
 {
     if (!h || !in || !out) return fail(SR_ERR_BAD_ARG, "null argument");

@@ -187,6 +187,16 @@ class Engine:
         self._check(self.L.sr_dtw_batch(self.h, _vp(in_mfcc), _vp(in_frames), C.c_uint32(B), _vp(sc), _vp(res)))
         return sc, res
 
+    def dtw_dp(self, in_mfcc, in_frames):
+        """OPT-IN non-reference scorer: full-DP DTW scores [B, K] (see sr_dtw_dp_batch)."""
+        in_mfcc = np.ascontiguousarray(in_mfcc, dtype=np.int16)
+        assert in_mfcc.shape[1:] == (self.max_frames, N_COEF)
+        in_frames = np.ascontiguousarray(in_frames, dtype=np.uint32)
+        B = in_mfcc.shape[0]
+        sc = np.zeros((B, self.n_templates), dtype=np.uint32)
+        self._check(self.L.sr_dtw_dp_batch(self.h, _vp(in_mfcc), _vp(in_frames), C.c_uint32(B), _vp(sc)))
+        return sc
+
     def fft_q15(self, words):
         """cr4_fft_1024_stm32 on uint32 [n, 1024] packed complex arrays."""
         words = np.ascontiguousarray(words, dtype=np.uint32)

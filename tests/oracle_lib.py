@@ -181,6 +181,17 @@ def _oracle_recognize_segments(self, pcm, tpl):
 Oracle.recognize_segments = _oracle_recognize_segments
 
 
+def _oracle_dtw_dp(self, a, na, b, nb):
+    """NON-REFERENCE extension: full-DP DTW (own definition, sr_oracle.c)."""
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    b = np.ascontiguousarray(b, dtype=np.int16)
+    self.L.sr_oracle_dtw_dp.restype = C.c_uint32
+    return self.L.sr_oracle_dtw_dp(_p(a), C.c_uint32(na), _p(b), C.c_uint32(nb), C.c_uint32(self.n_coef))
+
+
+Oracle.dtw_dp = _oracle_dtw_dp
+
+
 class RefLib:
     """Tier (i): the reference's own objects.  Non-reentrant (file-scope statics): single thread only."""
     FTR_BYTES = 2860  # sizeof(v_ftr_tag) at vv_frm_max = 119 (MFCC.H:18-25)

@@ -297,3 +297,26 @@ def test_train_store_matches_reference_layout(golden):
     out = e.recognize(pcm)
     assert np.array_equal(out["results"]["best_tpl"], slots[:B]) and (out["results"]["min_dis"] == 0).all()
     e.close()
+
+
+def test_dtw_dp_extension_matches_its_oracle():
+    """opt-in NON-REFERENCE full-DP scorer (wavefront across the wave) against its own CPU definition;
+    also sanity: D(a,a) = 0, and DP never exceeds the cost of ANY monotone path it allows (diagonal of equal lengths)"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(77)
+    maxf, K, B = 150, 9, 24
+    orc = ol.Oracle(max_frames=maxf)
+    tf = np.array([1, 2, 40, 64, 65, 100, 128, 129, 150], np.uint32)
+    tm = rng.integers(-2500, 2500, (K, maxf + 1, 12)).astype(np.int16)
+    inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
+    inf[:4] = (64, 65, 128, 150)
+    im = rng.integers(-2500, 2500, (B, maxf, 12)).astype(np.int16)
+    im[0, :64] = tm[3, :64]  # identical sequence -> score 0
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf)
+    sc = eng.dtw_dp(im, inf)
+    want = np.array([[orc.dtw_dp(im[b], inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)], dtype=np.uint32)
+    assert np.array_equal(sc, want)
+    assert sc[0, 3] == 0
+    assert (want == ol.DIS_ERR).sum() > 10 and (want != ol.DIS_ERR).sum() > 40
+    eng.close()
