@@ -172,6 +172,10 @@ int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
 
+/* diagnostics: per-utterance ballots of the VAD "loud" decision (VAD.C:164), 63 frames per 64-bit word, 16 words */
+int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                       sr_vad_rec *vad, uint64_t *masks);
+
 /* ------------------------------------------------------------------ reference-compatible scalar symbols
  * Exact reference signatures (u8/u16/u32/s16 = stdint fixed widths, stm32f10x.h:421-439).
  * Each one replaces the reference function cited; all run on the GPU through an implicit

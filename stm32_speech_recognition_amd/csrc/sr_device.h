@@ -43,6 +43,7 @@ struct MfccArgs {
     int16_t *mfcc;          // [B][max_frames][12]
     uint32_t tiles;         // frame tiles per utterance
     uint32_t n_items;       // B * tiles
+    uint32_t grid_cap;      // resident workgroups of k_mfcc on this device (0 = default)
     DevTables t;
 };
 
@@ -70,6 +71,8 @@ void launch_vad(const VadArgs &a, hipStream_t s);
 void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
                            hipStream_t s);
 void launch_mfcc(const MfccArgs &a, hipStream_t s);
+uint32_t mfcc_frames_per_tile();       // frames one work item of k_mfcc covers
+uint32_t mfcc_resident_workgroups();   // occupancy x CUs on the current device
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer

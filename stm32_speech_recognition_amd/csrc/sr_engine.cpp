@@ -58,6 +58,7 @@ struct sr_engine {
     sr_config cfg;
     int device = 0;
     uint32_t noise_len = 0, atap_frm = 0;
+    uint32_t mfcc_tile = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item, resident workgroups
     HostTables host;
     DevTables dev{};
     void *table_blob = nullptr;
@@ -144,6 +145,8 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->device = dev;
     h->noise_len = noise_len;
     h->atap_frm = atap_frm;
+    h->mfcc_tile = mfcc_frames_per_tile();
+    h->mfcc_grid_cap = mfcc_resident_workgroups();
     build_tables(h->host);
     // one blob, 16-byte aligned sub-tables
     const HostTables &t = h->host;
@@ -374,7 +377,8 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.max_frames = h->cfg.max_frames;
     a.vad = d_vad;
     a.mfcc = d_mfcc;
-    a.tiles = (h->cfg.max_frames + 63) / 64;  // kFramesPerTile in sr_kernels.hip
+    a.tiles = (h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile;
+    a.grid_cap = h->mfcc_grid_cap;
     a.n_items = B * a.tiles;
     a.t = h->dev;
     return a;
@@ -384,7 +388,7 @@ int sr_mfcc_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, 
                       int16_t *d_mfcc, void *stream)
 {
     if (!h || !d_pcm || !d_vad || !d_mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
-    if ((uint64_t)B * ((h->cfg.max_frames + 63) / 64) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
+    if ((uint64_t)B * ((h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
     HIP_TRY(hipSetDevice(h->device));
     launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, d_vad, d_mfcc), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -435,7 +439,7 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
     if (B == 0) return SR_OK;
     int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
     if (rc) return rc;
-    if ((uint64_t)B * ((h->cfg.max_frames + 63) / 64) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
+    if ((uint64_t)B * ((h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (!d_vad) {

@@ -558,22 +558,26 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     }
 }
 
+uint32_t mfcc_frames_per_tile() { return kFramesPerTile; }
+
+// workgroups of k_mfcc that fit on the current device at once (occupancy query x CU count)
+uint32_t mfcc_resident_workgroups()
+{
+    int dev = 0, n_cu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc, 64 * kMfccWaves,
+                                                     (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t)) != hipSuccess ||
+        per_cu < 1)
+        return 0;
+    return (uint32_t)(per_cu * n_cu);
+}
+
 void launch_mfcc(const MfccArgs &a, hipStream_t s)
 {
     if (a.n_items == 0) return;
     // persistent-style grid: exactly the workgroups that are resident at once, work items strided
-    static int per_cu = 0, n_cu = 0;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc, 64 * kMfccWaves,
-                                                         (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t)) != hipSuccess ||
-            per_cu < 1)
-            per_cu = 2;
-        if (n_cu < 1) n_cu = 256;
-    }
-    const uint32_t cap = (uint32_t)(per_cu * n_cu);
+    const uint32_t cap = a.grid_cap ? a.grid_cap : 1024u;
     const uint32_t grid = a.n_items < cap ? a.n_items : cap;
     const size_t lds = (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t);
     hipLaunchKernelGGL(k_mfcc, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
@@ -1036,16 +1040,6 @@ __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
     return (uint32_t)sqrt_rn_int((float)d);
 }
 
-__device__ __forceinline__ int dot12(const uint2 (&a)[3], const uint2 (&b)[3])
-{
-    int acc = sdot2z(a[0].x, b[0].x);
-    acc = sdot2(a[0].y, b[0].y, acc);
-    acc = sdot2(a[1].x, b[1].x, acc);
-    acc = sdot2(a[1].y, b[1].y, acc);
-    acc = sdot2(a[2].x, b[2].x, acc);
-    acc = sdot2(a[2].y, b[2].y, acc);
-    return acc;
-}
 
 struct DtwLdsArgs {
     DtwArgs d;

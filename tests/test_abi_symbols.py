@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary (no compute calls, no GPU needed):
+the in-tree C-ABI library loads and exports every function include/sr_engine.h declares, the struct
+layouts match the header, and without a GPU the product refuses to run (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from stm32_speech_recognition_amd import SrError, engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sr_engine.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)          # comments
+    src = re.sub(r"#pragma[^\n]*", " ", src)
+    src = re.sub(r"typedef\s+struct\s*\w*\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)  # struct bodies
+    names = re.findall(r"\b([A-Za-z_]\w*)\s*\([^;{}]*\)\s*;", src)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_header_declares_the_reference_entry_points():
+    names = declared_functions()
+    for n in ("noise_atap", "VAD", "get_mfcc", "fft", "cr4_fft_1024_stm32", "get_dis", "dtw_limit", "dtw", "spch_recg",
+              "GetMfcc", "MFCC_Comp", "sr_create", "sr_set_templates", "sr_recognize_batch", "sr_recognize_batch_dev",
+              "sr_mfcc_batch", "sr_dtw_batch", "sr_train_store", "sr_recognize_segments_batch"):
+        assert n in names, n
+    assert len(names) >= 30
+
+
+def test_library_exports_every_declared_symbol():
+    L = engine.load_library()
+    missing = [n for n in declared_functions() if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_header():
+    assert engine.RESULT_DTYPE.itemsize == 16 and engine.VAD_DTYPE.itemsize == 48
+    assert C.sizeof(engine.Config) == 40
+    from stm32_speech_recognition_amd import compat
+    assert C.sizeof(compat.v_ftr_tag) == 2860 and C.sizeof(compat.atap_tag) == 12
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    with pytest.raises(SrError, match="no HIP device|ROCm-capable|gfx950"):
+        engine.Engine()
