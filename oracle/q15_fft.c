@@ -178,3 +178,95 @@ void cr4_fft_1024_stm32(void *pssOUT, void *pssIN, uint16_t Nbin)
         tw_base += 3 * q;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * EXTENSION -- no reference counterpart (the reference's FFT "can only convert 1024 points", .s:214-215;
+ * BASELINE.json configs[4] asks for a 512-point front end).  Definition used by oracle and device alike:
+ *
+ *   fft256: the same ST radix-4 structure at 256 points: bit-reversed first pass (legs 64 words apart, loaded
+ *           A, C, B, D as in .s:134-145) + three twiddled passes with the N = 16, 64, 256 blocks of the same
+ *           coefficient table; output scaled 1/256 with the same per-pass truncation.
+ *   fft512: E = fft256(even samples), O = fft256(odd samples), then one truncating radix-2 pass
+ *           X[k]     = (E[k] + O[k]*conj(W[k])) >> 1      W[k] = Q14 (cos, sin)(2*pi*k/512), rounded half away,
+ *           X[k+256] = (E[k] - O[k]*conj(W[k])) >> 1      product O*conj(W) taken >> 14 (arithmetic) before the add;
+ *           results stored as 16+16 bits like every other pass.  Output scaled 1/512.
+ * ------------------------------------------------------------------------------------------------ */
+static inline unsigned bitrev6(unsigned v) { return bitrev8(v) >> 2; }
+
+void sr_oracle_q15_fft256(uint32_t *out, const uint32_t *in)
+{
+    tw_init();
+    for (unsigned idx = 0; idx < 64; idx++) {
+        unsigned r = bitrev6(idx);
+        int32_t ar = lo16(in[r]), ai = hi16(in[r]);
+        int32_t cr = lo16(in[r + 64]), ci = hi16(in[r + 64]);
+        int32_t br = lo16(in[r + 128]), bi = hi16(in[r + 128]);
+        int32_t dr = lo16(in[r + 192]), di = hi16(in[r + 192]);
+        r4_combine(&ar, &ai, &br, &bi, &cr, &ci, &dr, &di, 0);
+        out[4 * idx + 0] = pack16(ar, ai);
+        out[4 * idx + 1] = pack16(br, bi);
+        out[4 * idx + 2] = pack16(cr, ci);
+        out[4 * idx + 3] = pack16(di, dr);
+    }
+    int tw_base = 0;
+    for (int q = 4; q < 256; q *= 4) {
+        for (int g = 0; g < 256; g += 4 * q) {
+            int k = tw_base;
+            for (int b = 0; b < q; b++, k += 3) {
+                int j = g + b;
+                int32_t ar, ai, br, bi, cr, ci, dr, di;
+                uint32_t w;
+                w = out[j + 3 * q];
+                cxmul(&dr, &di, lo16(w), hi16(w), tw_kr[k + 0], tw_ki[k + 0]);
+                w = out[j + 2 * q];
+                cxmul(&cr, &ci, lo16(w), hi16(w), tw_kr[k + 1], tw_ki[k + 1]);
+                w = out[j + q];
+                cxmul(&br, &bi, lo16(w), hi16(w), tw_kr[k + 2], tw_ki[k + 2]);
+                w = out[j];
+                ar = lo16(w);
+                ai = hi16(w);
+                r4_combine(&ar, &ai, &br, &bi, &cr, &ci, &dr, &di, 14);
+                out[j] = pack16(ar, ai);
+                out[j + q] = pack16(br, bi);
+                out[j + 2 * q] = pack16(cr, ci);
+                out[j + 3 * q] = pack16(di, dr);
+            }
+        }
+        tw_base += 3 * q;
+    }
+}
+
+void sr_oracle_q15_w512(int16_t *wc, int16_t *ws)
+{
+    for (int k = 0; k < 256; k++) {
+        double t = 2.0 * M_PI * (double)k / 512.0;
+        wc[k] = round_q14(16384.0 * cos(t));
+        ws[k] = round_q14(16384.0 * sin(t));
+    }
+}
+
+void sr_oracle_q15_fft512(uint32_t *out, const uint32_t *in)
+{
+    static int16_t wc[256], ws[256];
+    static int w_ready;
+    uint32_t ev[256], od[256], E[256], O[256];
+    if (!w_ready) {
+        sr_oracle_q15_w512(wc, ws);
+        w_ready = 1;
+    }
+    for (int i = 0; i < 256; i++) {
+        ev[i] = in[2 * i];
+        od[i] = in[2 * i + 1];
+    }
+    sr_oracle_q15_fft256(E, ev);
+    sr_oracle_q15_fft256(O, od);
+    for (int k = 0; k < 256; k++) {
+        int32_t orr = lo16(O[k]), oi = hi16(O[k]);
+        /* O * conj(W) in Q14, then >> 14 */
+        int32_t pr = asr(wadd(wmul(orr, wc[k]), wmul(oi, ws[k])), 14);
+        int32_t pi = asr(wsub(wmul(oi, wc[k]), wmul(orr, ws[k])), 14);
+        int32_t er = lo16(E[k]), ei = hi16(E[k]);
+        out[k] = pack16(asr(wadd(er, pr), 1), asr(wadd(ei, pi), 1));
+        out[k + 256] = pack16(asr(wsub(er, pr), 1), asr(wsub(ei, pi), 1));
+    }
+}

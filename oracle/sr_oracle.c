@@ -11,6 +11,7 @@
 #include <string.h>
 
 void cr4_fft_1024_stm32(void *pssOUT, void *pssIN, uint16_t Nbin); /* q15_fft.c */
+void sr_oracle_q15_fft512(uint32_t *out, const uint32_t *in);        /* q15_fft.c, EXTENSION */
 
 struct sr_oracle {
     sr_oracle_cfg cfg;
@@ -114,7 +115,9 @@ static void gen_dct(sr_oracle *o)
 sr_oracle *sr_oracle_create(const sr_oracle_cfg *cfg)
 {
     sr_oracle *o;
-    if (cfg->nfft != 1024 || (cfg->n_mel & 1) || cfg->n_mel < 4 || cfg->max_frames == 0 || cfg->max_frames > 16383)
+    /* nfft 512 = the EXTENSION front end (no reference counterpart) */
+    if ((cfg->nfft != 1024 && cfg->nfft != 512) || (cfg->n_mel & 1) || cfg->n_mel < 4 || cfg->n_mel > 64 ||
+        cfg->max_frames == 0 || cfg->max_frames > 16383)
         return NULL;
     o = calloc(1, sizeof(*o));
     o->cfg = *cfg;
@@ -270,7 +273,10 @@ int sr_oracle_fft_mag(const sr_oracle *o, const int16_t *frame, uint32_t len, ui
         return 1;
     for (uint32_t i = 0; i < len; i++) in[i] = (uint16_t)frame[i]; /* imag = 0 in the high half */
     for (uint32_t i = len; i < o->cfg.nfft; i++) in[i] = 0;
-    cr4_fft_1024_stm32(out, in, (uint16_t)o->cfg.nfft);
+    if (o->cfg.nfft == 1024)
+        cr4_fft_1024_stm32(out, in, 1024);
+    else
+        sr_oracle_q15_fft512(out, in);
     for (uint32_t i = 0; i < o->frq_max; i++) {
         int32_t re = (int16_t)out[i], im = (int16_t)(out[i] >> 16);
         int32_t r = re * re + im * im;

@@ -18,6 +18,8 @@ struct DevTables {
     const uint32_t *tw_a;      // [1020]
     const uint32_t *tw_b;      // [1020]
     const uint32_t *log_thr;   // [2220]
+    const uint32_t *w512_a;    // [256]  EXTENSION front end only
+    const uint32_t *w512_b;    // [256]
 };
 
 struct VadArgs {
@@ -32,6 +34,7 @@ struct VadArgs {
     sr_vad_rec *vad;      // [B]
     const sr_atap *atap_in;  // optional [B]: use these thresholds instead of running noise_atap
     uint64_t *dbg_masks;     // optional [B][16]: per-round ballot of "loud" frames (diagnostics)
+    uint32_t frame_len;      // 160 (reference) or 320 (extension)
 };
 
 struct MfccArgs {
@@ -44,6 +47,7 @@ struct MfccArgs {
     uint32_t tiles;         // frame tiles per utterance
     uint32_t n_items;       // B * tiles
     uint32_t grid_cap;      // resident workgroups of k_mfcc on this device (0 = default)
+    uint32_t frame_len;     // 160 -> k_mfcc (reference front end), 320 -> k_mfcc_ext (extension)
     DevTables t;
 };
 
@@ -69,10 +73,10 @@ struct DtwArgs {
 
 void launch_vad(const VadArgs &a, hipStream_t s);
 void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
-                           hipStream_t s);
+                           uint32_t frame_len, uint32_t hop, hipStream_t s);
 void launch_mfcc(const MfccArgs &a, hipStream_t s);
-uint32_t mfcc_frames_per_tile();       // frames one work item of k_mfcc covers
-uint32_t mfcc_resident_workgroups();   // occupancy x CUs on the current device
+uint32_t mfcc_frames_per_tile(uint32_t frame_len);      // frames one work item of the frame kernel covers
+uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on the current device
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer

@@ -59,6 +59,7 @@ struct sr_engine {
     int device = 0;
     uint32_t noise_len = 0, atap_frm = 0;
     uint32_t mfcc_tile = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item, resident workgroups
+    uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension
     HostTables host;
     DevTables dev{};
     void *table_blob = nullptr;
@@ -125,15 +126,18 @@ int sr_create(const sr_config *cfg, sr_engine **out)
 {
     if (!cfg || !out) return fail(SR_ERR_BAD_ARG, "null argument");
     *out = nullptr;
-    // The kernels are specialised for the reference's framing (see sr_tables.h); other sample
-    // rates / FFT sizes are the "extension" configuration and are not built yet.
-    if (cfg->fs != 8000 || cfg->frame_time_ms != 20 || cfg->frame_mov_ms != 10 || cfg->nfft != 1024 ||
-        cfg->n_mel != 24 || cfg->n_coef != 12)
-        return fail(SR_ERR_BAD_CONFIG, "only fs=8000, 20/10 ms framing, nfft=1024, 24 Mel, 12 MFCC is supported");
+    // Two front ends are built: the reference's (8 kHz, 160/80 framing, 1024-point FFT, 24 Mel) and the
+    // 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
+    const bool is_ref = cfg->fs == 8000 && cfg->nfft == 1024 && cfg->n_mel == 24;
+    const bool is_ext = cfg->fs == 16000 && cfg->nfft == 512 && cfg->n_mel == 40;
+    if (!(is_ref || is_ext) || cfg->frame_time_ms != 20 || cfg->frame_mov_ms != 10 || cfg->n_coef != 12)
+        return fail(SR_ERR_BAD_CONFIG,
+                    "supported: fs=8000/nfft=1024/24 Mel (reference) or fs=16000/nfft=512/40 Mel (extension), 20/10 ms, 12 MFCC");
+    const FrontEnd fe = is_ext ? kFrontExt : kFrontRef;
     if (cfg->max_frames < 2 || cfg->max_frames > 16383) return fail(SR_ERR_BAD_CONFIG, "max_frames must be 2..16383");
     if (cfg->max_seg < 1 || cfg->max_seg > SR_MAX_SEG) return fail(SR_ERR_BAD_CONFIG, "max_seg must be 1..3");
     const uint32_t noise_len = (cfg->fs / 1000) * cfg->noise_len_ms, atap_frm = (cfg->fs / 1000) * 30;
-    if (noise_len == 0 || noise_len % atap_frm != 0 || noise_len % kFrameLen != 0)
+    if (noise_len == 0 || noise_len % atap_frm != 0 || noise_len % (uint32_t)fe.frame_len != 0)
         return fail(SR_ERR_BAD_CONFIG, "noise_len_ms must be a non-zero multiple of 60 ms");
     int dev = 0;
     int rc = check_device(cfg->device, &dev);
@@ -145,19 +149,22 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->device = dev;
     h->noise_len = noise_len;
     h->atap_frm = atap_frm;
-    h->mfcc_tile = mfcc_frames_per_tile();
-    h->mfcc_grid_cap = mfcc_resident_workgroups();
-    build_tables(h->host);
+    h->frame_len = (uint32_t)fe.frame_len;
+    h->hop = (uint32_t)fe.hop;
+    h->mfcc_tile = mfcc_frames_per_tile(h->frame_len);
+    h->mfcc_grid_cap = mfcc_resident_workgroups(h->frame_len);
+    build_tables(h->host, fe);
     // one blob, 16-byte aligned sub-tables
     const HostTables &t = h->host;
     struct Part {
         const void *src;
         size_t bytes;
         size_t off;
-    } parts[8] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
+    } parts[10] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
                   {t.tri_odd.data(), t.tri_odd.size() * 2, 0}, {t.tri_cen.data(), t.tri_cen.size() * 2, 0},
                   {t.dct.data(), t.dct.size(), 0},             {t.tw_a.data(), t.tw_a.size() * 4, 0},
-                  {t.tw_b.data(), t.tw_b.size() * 4, 0},       {t.log_thr.data(), t.log_thr.size() * 4, 0}};
+                  {t.tw_b.data(), t.tw_b.size() * 4, 0},       {t.log_thr.data(), t.log_thr.size() * 4, 0},
+                  {t.w512_a.data(), t.w512_a.size() * 4, 0},   {t.w512_b.data(), t.w512_b.size() * 4, 0}};
     size_t total = 0;
     for (auto &p : parts) {
         p.off = total;
@@ -180,6 +187,8 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->dev.tw_a = (const uint32_t *)(base + parts[5].off);
     h->dev.tw_b = (const uint32_t *)(base + parts[6].off);
     h->dev.log_thr = (const uint32_t *)(base + parts[7].off);
+    h->dev.w512_a = (const uint32_t *)(base + parts[8].off);
+    h->dev.w512_b = (const uint32_t *)(base + parts[9].off);
     *out = h;
     return SR_OK;
 }
@@ -349,7 +358,7 @@ static int check_pcm(const sr_engine *h, const uint16_t *pcm, uint64_t stride, u
     if (!pcm) return fail(SR_ERR_BAD_ARG, "null pcm");
     if (((uintptr_t)pcm & 15) || (stride & 7)) return fail(SR_ERR_BAD_ARG, "pcm must be 16-byte aligned, stride % 8 == 0");
     if (buf_len > stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
-    if (buf_len < h->noise_len || buf_len <= (uint32_t)kFrameLen) return fail(SR_ERR_BAD_ARG, "buf_len shorter than the noise head");
+    if (buf_len < h->noise_len || buf_len <= h->frame_len) return fail(SR_ERR_BAD_ARG, "buf_len shorter than the noise head");
     if (buf_len > 0x7FFFFFF0u) return fail(SR_ERR_BAD_ARG, "buf_len too large");
     return SR_OK;
 }
@@ -361,7 +370,7 @@ int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, u
     int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    VadArgs a{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr};
+    VadArgs a{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr, h->frame_len};
     launch_vad(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SR_OK;
@@ -379,6 +388,7 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.mfcc = d_mfcc;
     a.tiles = (h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile;
     a.grid_cap = h->mfcc_grid_cap;
+    a.frame_len = h->frame_len;
     a.n_items = B * a.tiles;
     a.t = h->dev;
     return a;
@@ -464,7 +474,7 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
         }
         ev = &h->ev[5 * h->ev_used];
     }
-    VadArgs va{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr};
+    VadArgs va{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr, h->frame_len};
     if (prof) HIP_TRY(hipEventRecord(ev[0], s));
     launch_vad(va, s);
     if (prof) HIP_TRY(hipEventRecord(ev[1], s));
@@ -505,10 +515,10 @@ int sr_recognize_segments_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_
         if ((rc = h->s_scores.reserve((size_t)B * h->K * h->cfg.max_seg))) return rc;
         d_scores = h->s_scores.p;
     }
-    VadArgs va{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr};
+    VadArgs va{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr, h->frame_len};
     launch_vad(va, s);
     for (uint32_t sg = 0; sg < h->cfg.max_seg; sg++) {
-        launch_select_segment(d_vad, h->s_vad2.p, B, sg, h->cfg.max_frames, s);
+        launch_select_segment(d_vad, h->s_vad2.p, B, sg, h->cfg.max_frames, h->frame_len, h->hop, s);
         launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, h->s_vad2.p, h->s_mfcc.p), s);
         DtwArgs da = dtw_args(h, h->s_mfcc.p, h->s_vad2.p, nullptr, B, d_scores + (size_t)sg * B * h->K,
                               d_results + (size_t)sg * B);
@@ -611,7 +621,7 @@ int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
     DevBuf<uint64_t> dm;
     if ((rc = dm.reserve((size_t)B * 16))) return rc;
     HIP_TRY(hipMemset(dm.p, 0, (size_t)B * 16 * 8));
-    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, h->s_vad.p, nullptr, dm.p};
+    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, h->s_vad.p, nullptr, dm.p, h->frame_len};
     launch_vad(a, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
@@ -636,9 +646,9 @@ int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32
         for (int i = 0; i < 2 * SR_MAX_SEG; i++) r.seg[i] = -1;
         r.seg[0] = start[b];
         r.seg[1] = end[b];
-        if (start[b] < 1 || end[b] > (int32_t)buf_len || end[b] - start[b] < kFrameLen)
+        if (start[b] < 1 || end[b] > (int32_t)buf_len || end[b] - start[b] < (int32_t)h->frame_len)
             return fail(SR_ERR_BAD_ARG, "segment outside the buffer (start must be >= 1: MFCC.C:119 reads start[-1])");
-        const uint32_t n = ((((uint32_t)(end[b] - start[b]) - kFrameLen) / kHop) + 1) & 0xFFFF;  // MFCC.C:102
+        const uint32_t n = ((((uint32_t)(end[b] - start[b]) - h->frame_len) / h->hop) + 1) & 0xFFFF;  // MFCC.C:102
         r.status = n > h->cfg.max_frames ? SR_ST_MFCC_FAIL : SR_ST_OK;                           // MFCC.C:103-107
         r.frm_num = n > h->cfg.max_frames ? 0 : n;
         if (frm_num) frm_num[b] = r.frm_num;
@@ -827,7 +837,7 @@ int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, co
     if ((rc = h->s_vad.reserve(1))) return rc;
     if ((rc = h->s_atap.reserve(1))) return rc;
     HIP_TRY(hipMemcpy(h->s_atap.p, atap, sizeof(sr_atap), hipMemcpyHostToDevice));
-    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, h->s_atap.p, nullptr};
+    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, h->s_atap.p, nullptr, h->frame_len};
     launch_vad(a, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(rec, h->s_vad.p, sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
@@ -843,7 +853,7 @@ int engine_noise_atap(sr_engine *h, const uint16_t *noise, uint32_t n_len, sr_at
     int rc = stage_pcm(h, noise, n_len, n_len, 1, &ds);
     if (rc) return rc;
     if ((rc = h->s_vad.reserve(1))) return rc;
-    VadArgs a{h->s_pcm.p, ds, n_len, n_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, nullptr, nullptr};
+    VadArgs a{h->s_pcm.p, ds, n_len, n_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, nullptr, nullptr, h->frame_len};
     launch_vad(a, nullptr);
     HIP_TRY(hipGetLastError());
     sr_vad_rec rec;

@@ -558,18 +558,187 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     }
 }
 
-uint32_t mfcc_frames_per_tile() { return kFramesPerTile; }
+// ------------------------------------------------------------------------------------------------
+// k_mfcc_ext: EXTENSION front end (BASELINE.json configs[4]: 16 kHz, 20/10 ms framing = 320/160 samples,
+// 512-point transform, 40 Mel filters, 12 coefficients).  No reference counterpart: the reference's FFT only
+// converts 1024 points (.s:214-215).  Same arithmetic rules as get_mfcc (MFCC.C:86-191) with the tables generated
+// from the same Matlab formulas at fs = 16000; the 512-point transform is two ST-style 256-point radix-4
+// transforms (even / odd samples) + one truncating radix-2 pass, as defined in oracle/q15_fft.c.
+// One wave per frame; every pass goes through LDS (64 radix-4 butterflies per 256-point pass = one per lane).
+// Correctness-first: this kernel is not tuned like k_mfcc.
+// ------------------------------------------------------------------------------------------------
+namespace ext {
+constexpr int kFL = 320, kHopE = 160, kBinsE = 256, kMelE = 40;
+constexpr int kWaves = 4, kFpw = 8, kTile = kWaves * kFpw;
+constexpr int kWaveWords = 512 + 512 + kFpw * kMelE;  // two 256-word sub-arrays, scratch, filterbank outputs
+}  // namespace ext
 
-// workgroups of k_mfcc that fit on the current device at once (occupancy query x CU count)
-uint32_t mfcc_resident_workgroups()
+__device__ __forceinline__ int bitrev6(int v) { return (int)(__brev((uint32_t)v) >> 26); }
+
+__global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
+{
+    using namespace ext;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ int8_t s_dct[kCoef * kMelE];
+    __shared__ uint16_t s_hamm[kFL];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *work = smem + w * kWaveWords;  // [2][256] packed samples of the even / odd sub-transform
+    uint32_t *aux = work + 512;              // [2][256] pass outputs, later prefix sums
+    uint32_t *powb = aux + 512;
+    for (int i = threadIdx.x; i < kCoef * kMelE; i += blockDim.x) s_dct[i] = a.t.dct[i];
+    for (int i = threadIdx.x; i < kFL; i += blockDim.x) s_hamm[i] = a.t.hamm[i];
+    __syncthreads();
+
+    uint32_t tri_e[4], tri_o[4];  // triangle weights of bins 4*lane .. 4*lane+3
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        tri_e[k] = a.t.tri_even[4 * lane + k];
+        tri_o[k] = a.t.tri_odd[4 * lane + k];
+    }
+    int f_lo = 0, f_hi = 0;
+    if (lane < kMelE) {
+        f_lo = (lane == 0) ? 0 : (int)a.t.tri_cen[lane - 1];
+        f_hi = (lane == kMelE - 1) ? kBinsE : (int)a.t.tri_cen[lane + 1];
+    }
+
+    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const uint32_t b = item / a.tiles, tile = item - b * a.tiles;
+        const sr_vad_rec *rec = a.vad + b;
+        const uint32_t nfrm = rec->frm_num;
+        const int mid = (int)rec->atap.mid_val, seg0 = rec->seg[0];
+        const uint16_t *row = a.pcm + (uint64_t)b * a.pcm_stride;
+        int16_t *out = a.mfcc + (uint64_t)b * a.max_frames * kCoef;
+        const uint32_t f0 = tile * kTile + w * kFpw;
+        uint32_t nf = 0;
+        if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFpw) ? nfrm - f0 : (uint32_t)kFpw;
+
+        for (uint32_t fi = 0; fi < nf; fi++) {
+            const uint16_t *x = row + seg0 + kHopE * (int)(f0 + fi);
+            // pre-emphasis + Hamming (MFCC.C:115-124); sample i goes to sub-array i&1, slot i>>1; rest zero
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int i = lane + 64 * k;
+                const int cur = (int)x[i] - mid, prv = (int)x[i - 1] - mid;
+                const int t = cur - prv * 95 / 100;
+                work[(i & 1) * 256 + (i >> 1)] = (uint32_t)(t * (int)s_hamm[i] / 1000) & 0xFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int z = lane + 64 * k;  // 2 x 96 padding words
+                work[(z / 96) * 256 + 160 + (z % 96)] = 0u;
+            }
+            wave_sync();
+            // pass 1 of both 256-point transforms: work -> aux (bit-reversed gather, legs 64 words apart)
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const uint32_t *src = work + sub * 256;
+                const int r = bitrev6(lane);
+                const uint32_t wa = src[r], wc = src[r + 64], wb = src[r + 128], wd = src[r + 192];
+                int ar = sext_lo(wa), ai = sext_hi(wa), br = sext_lo(wb), bi = sext_hi(wb);
+                int cr = sext_lo(wc), ci = sext_hi(wc), dr = sext_lo(wd), di = sext_hi(wd);
+                r4_combine<0>(ar, ai, br, bi, cr, ci, dr, di);
+                uint32_t *dst = aux + sub * 256 + 4 * lane;
+                dst[0] = pack16(ar, ai);
+                dst[1] = pack16(br, bi);
+                dst[2] = pack16(cr, ci);
+                dst[3] = pack16(di, dr);
+            }
+            wave_sync();
+            // passes 2-4 (q = 4, 16, 64) in place; coefficient blocks N = 16, 64, 256 of the ST table
+            int tw_base = 0;
+#pragma unroll
+            for (int q = 4; q <= 64; q *= 4) {
+                const int bq = lane & (q - 1), j = ((lane / q) * 4 * q) + bq;
+                uint32_t k3[3][2];
+                load_tw3(a.t, tw_base, bq, k3);
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+                    uint32_t *p = aux + sub * 256 + j;
+                    uint32_t x0 = p[0], x1 = p[q], x2 = p[2 * q], x3 = p[3 * q];
+                    bfly(x0, x1, x2, x3, k3[0][0], k3[0][1], k3[1][0], k3[1][1], k3[2][0], k3[2][1]);
+                    p[0] = x0;
+                    p[q] = x1;
+                    p[2 * q] = x2;
+                    p[3 * q] = x3;
+                }
+                tw_base += 3 * q;
+                wave_sync();
+            }
+            // radix-2 pass for bins < 256: X[k] = (E[k] + O[k]*conj(W[k]) >> 14) >> 1, then |X|*10 and energy
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int kb = lane + 64 * m;
+                const uint32_t e = aux[kb], o = aux[256 + kb];
+                int pr, pi;
+                cxmul(o, a.t.w512_a[kb], a.t.w512_b[kb], pr, pi);
+                const int re = (int)(short)((sext_lo(e) + (pr >> 14)) >> 1), im = (int)(short)((sext_hi(e) + (pi >> 14)) >> 1);
+                const int r = re * re + im * im;
+                const uint32_t mag = (uint32_t)(sqrt_rn_int((float)r) * 10.0f);
+                work[kb] = mag * mag;
+            }
+            wave_sync();
+            // Mel filterbank via prefix sums (MFCC.C:136-162 at 40 filters / 256 bins)
+            uint32_t pe[4], po[4];
+            {
+                const u32x4 q0 = *(const u32x4 *)(work + 4 * lane);
+                const uint32_t e[4] = {q0.x, q0.y, q0.z, q0.w};
+                uint32_t se = 0, so = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    se += e[k] * tri_e[k] / 100u;
+                    so += e[k] * tri_o[k] / 100u;
+                    pe[k] = se;
+                    po[k] = so;
+                }
+                const uint32_t xe = wave_scan_incl(se) - se, xo = wave_scan_incl(so) - so;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    pe[k] += xe;
+                    po[k] += xo;
+                }
+            }
+            *(u32x4 *)(aux + 4 * lane) = u32x4{pe[0], pe[1], pe[2], pe[3]};
+            *(u32x4 *)(aux + kBinsE + 4 * lane) = u32x4{po[0], po[1], po[2], po[3]};
+            wave_sync();
+            if (lane < kMelE) {
+                const uint32_t *P = aux + ((lane & 1) ? kBinsE : 0);
+                const uint32_t hi = P[f_hi - 1], lo = f_lo ? P[f_lo - 1] : 0u;
+                powb[fi * kMelE + lane] = hi - lo;
+            }
+            wave_sync();
+        }
+        for (uint32_t t = lane; t < nf * kMelE; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr);
+        wave_sync();
+        for (uint32_t t = lane; t < nf * kCoef; t += 64) {
+            const uint32_t fi = t / kCoef, h = t - fi * kCoef;
+            int acc = 0;
+            for (int i = 0; i < kMelE; i++) acc += (int)powb[fi * kMelE + i] * (int)s_dct[h * kMelE + i] / 100;
+            out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
+        }
+        wave_sync();
+        {
+            const uint32_t r0 = f0 + nf, r1 = (f0 + kFpw < a.max_frames) ? f0 + kFpw : a.max_frames;
+            for (uint32_t t = r0 * kCoef + lane; t < r1 * kCoef && r0 < r1; t += 64) out[t] = 0;
+        }
+    }
+}
+
+uint32_t mfcc_frames_per_tile(uint32_t frame_len) { return frame_len == 320 ? (uint32_t)ext::kTile : (uint32_t)kFramesPerTile; }
+
+// workgroups of the frame kernel that fit on the current device at once (occupancy query x CU count)
+uint32_t mfcc_resident_workgroups(uint32_t frame_len)
 {
     int dev = 0, n_cu = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc, 64 * kMfccWaves,
-                                                     (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t)) != hipSuccess ||
-        per_cu < 1)
-        return 0;
+    hipError_t e;
+    if (frame_len == 320)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc_ext, 64 * ext::kWaves,
+                                                         (size_t)ext::kWaves * ext::kWaveWords * sizeof(uint32_t));
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc, 64 * kMfccWaves,
+                                                         (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t));
+    if (e != hipSuccess || per_cu < 1) return 0;
     return (uint32_t)(per_cu * n_cu);
 }
 
@@ -579,6 +748,11 @@ void launch_mfcc(const MfccArgs &a, hipStream_t s)
     // persistent-style grid: exactly the workgroups that are resident at once, work items strided
     const uint32_t cap = a.grid_cap ? a.grid_cap : 1024u;
     const uint32_t grid = a.n_items < cap ? a.n_items : cap;
+    if (a.frame_len == 320) {
+        const size_t lds = (size_t)ext::kWaves * ext::kWaveWords * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_mfcc_ext, dim3(grid), dim3(64 * ext::kWaves), lds, s, a);
+        return;
+    }
     const size_t lds = (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t);
     hipLaunchKernelGGL(k_mfcc, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
 }
@@ -690,6 +864,7 @@ constexpr int kVadWaves = 4;
 
 __device__ __forceinline__ uint32_t absdiff(uint32_t v, uint32_t mid) { return v > mid ? v - mid : mid - v; }
 
+template <int kFrameLen, int kHop>  // 160/80 = the reference (VAD.H:5-8); 320/160 = the 16 kHz extension
 __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -886,7 +1061,8 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
 
 // Re-targets the per-utterance records at VAD segment `seg_idx` (0..2): the frame and DTW kernels always work
 // on "segment 0" of the record they are given.  Frame count and status follow MFCC.C:102-107 / main.c:261-274.
-__global__ void k_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames)
+__global__ void k_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
+                                 uint32_t frame_len, uint32_t hop)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -900,23 +1076,28 @@ __global__ void k_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t
     } else if (st < 1) {
         r.status = SR_ST_SEG_OOB;
     } else {
-        const uint32_t n = ((((uint32_t)(en - st) - kFrameLen) / kHop) + 1) & 0xFFFF;
+        const uint32_t n = ((((uint32_t)(en - st) - frame_len) / hop) + 1) & 0xFFFF;
         r.status = n > max_frames ? SR_ST_MFCC_FAIL : SR_ST_OK;
         r.frm_num = n > max_frames ? 0 : n;
     }
     out[b] = r;
 }
 void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
-                           hipStream_t s)
+                           uint32_t frame_len, uint32_t hop, hipStream_t s)
 {
     if (!B) return;
-    hipLaunchKernelGGL(k_select_segment, dim3((B + 255) / 256), dim3(256), 0, s, in, out, B, seg_idx, max_frames);
+    hipLaunchKernelGGL(k_select_segment, dim3((B + 255) / 256), dim3(256), 0, s, in, out, B, seg_idx, max_frames,
+                       frame_len, hop);
 }
 
 void launch_vad(const VadArgs &a, hipStream_t s)
 {
     if (!a.B) return;
-    hipLaunchKernelGGL(k_vad, dim3((a.B + kVadWaves - 1) / kVadWaves), dim3(64 * kVadWaves), 0, s, a);
+    const dim3 grid((a.B + kVadWaves - 1) / kVadWaves), block(64 * kVadWaves);
+    if (a.frame_len == 320)
+        hipLaunchKernelGGL((k_vad<320, 160>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((k_vad<160, 80>), grid, block, 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

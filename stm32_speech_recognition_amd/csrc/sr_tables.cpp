@@ -8,20 +8,20 @@ namespace sr {
 static double mround(double v) { return v >= 0.0 ? std::floor(v + 0.5) : -std::floor(-v + 0.5); }
 
 // Hamming window scaled to hamm_top = 10000 (speech_recog.m:217-222, MFCC_Arg.h:6-9).
-static void gen_hamm(HostTables &t)
+static void gen_hamm(HostTables &t, const FrontEnd &fe)
 {
-    t.hamm.resize(kFrameLen);
-    for (int i = 0; i < kFrameLen; i++)
-        t.hamm[i] = (uint16_t)mround((0.54 - 0.46 * std::cos(2 * M_PI * i / (kFrameLen - 1))) * 10000.0);
+    t.hamm.resize(fe.frame_len);
+    for (int i = 0; i < fe.frame_len; i++)
+        t.hamm[i] = (uint16_t)mround((0.54 - 0.46 * std::cos(2 * M_PI * i / (fe.frame_len - 1))) * 10000.0);
 }
 
 // Mel triangle centres and the two interleaved triangle poly-lines (speech_recog.m:240-310).
 // The Matlab arrays are 1-based; element j is C index j-1, and Matlab's "odd" poly-line is the
 // C table tri_even (filters 0,2,4,...) and vice versa (MFCC_Arg.h:17-27).
-static void gen_tri(HostTables &t)
+static void gen_tri(HostTables &t, const FrontEnd &fe)
 {
-    const double top = 1000.0, fs = 8000.0;
-    const int n = kMel, nb = kBins;
+    const double top = 1000.0, fs = fe.fs;
+    const int n = fe.n_mel, nb = fe.bins;
     const double f_max = fs / 2;
     const double mel_max = 2595 * std::log10(1 + f_max / 700);
     const double mel_step = mel_max / (n + 1);
@@ -61,12 +61,26 @@ static void gen_tri(HostTables &t)
 }
 
 // 12 x 24 cosine table scaled by 100 (teat.m:19-26, MFCC_Arg.h:29-44).
-static void gen_dct(HostTables &t)
+static void gen_dct(HostTables &t, const FrontEnd &fe)
 {
-    t.dct.resize(kCoef * kMel);
+    const int nm = fe.n_mel;
+    t.dct.resize(kCoef * nm);
     for (int h = 1; h <= kCoef; h++)
-        for (int j = 1; j <= kMel; j++)
-            t.dct[(h - 1) * kMel + (j - 1)] = (int8_t)mround(std::cos(h * M_PI * (j - 0.5) / kMel) * 100);
+        for (int j = 1; j <= nm; j++)
+            t.dct[(h - 1) * nm + (j - 1)] = (int8_t)mround(std::cos(h * M_PI * (j - 0.5) / nm) * 100);
+}
+
+// EXTENSION: coefficients of the final radix-2 pass of the 512-point transform (see oracle/q15_fft.c)
+static void gen_w512(HostTables &t)
+{
+    t.w512_a.resize(256);
+    t.w512_b.resize(256);
+    for (int k = 0; k < 256; k++) {
+        const double th = 2.0 * M_PI * k / 512.0;
+        const int wc = (int)mround(16384.0 * std::cos(th)), ws = (int)mround(16384.0 * std::sin(th));
+        t.w512_a[k] = ((uint32_t)wc & 0xFFFFu) | ((uint32_t)ws << 16);
+        t.w512_b[k] = ((uint32_t)(-ws) & 0xFFFFu) | ((uint32_t)wc << 16);
+    }
 }
 
 // Coefficients of the ST radix-4 FFT: per pass N in {16,64,256,1024}, per butterfly b < N/4, three
@@ -118,13 +132,14 @@ static void gen_log_thr(HostTables &t)
     }
 }
 
-void build_tables(HostTables &t)
+void build_tables(HostTables &t, const FrontEnd &fe)
 {
-    gen_hamm(t);
-    gen_tri(t);
-    gen_dct(t);
+    gen_hamm(t, fe);
+    gen_tri(t, fe);
+    gen_dct(t, fe);
     gen_twiddles(t);
     gen_log_thr(t);
+    gen_w512(t);
 }
 
 }  // namespace sr

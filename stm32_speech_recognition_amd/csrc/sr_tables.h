@@ -17,6 +17,14 @@ constexpr int kCoef = 12;       // mfcc_num, MFCC.H:13
 constexpr int kTwiddles = 1020; // 3 per butterfly, passes N = 16, 64, 256, 1024
 constexpr int kLogMax = 2218;   // floor(100*ln(2^32-1))
 
+// The two front ends the kernels are built for: the reference's (ADC.H:7, VAD.H:5-8, MFCC.H:7-13) and the
+// 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
+struct FrontEnd {
+    int fs, frame_len, hop, nfft, bins, n_mel;
+};
+constexpr FrontEnd kFrontRef = {8000, 160, 80, 1024, 512, 24};
+constexpr FrontEnd kFrontExt = {16000, 320, 160, 512, 256, 40};
+
 struct HostTables {
     std::vector<uint16_t> hamm;      // [160]
     std::vector<uint16_t> tri_cen;   // [24]
@@ -31,8 +39,10 @@ struct HostTables {
     std::vector<int16_t> tw_kr, tw_ki; // raw (Kr', Ki) as in the .s table, for tests
     // log_thr[m] = smallest n with (u32)(log((double)n)*100) >= m, m = 0..2218; [2219] = sentinel.
     std::vector<uint32_t> log_thr;
+    // EXTENSION only: Q14 (cos, sin)(2*pi*k/512), k < 256, packed like the butterfly coefficients
+    std::vector<uint32_t> w512_a, w512_b;
 };
 
-void build_tables(HostTables &t);
+void build_tables(HostTables &t, const FrontEnd &fe);
 
 }  // namespace sr

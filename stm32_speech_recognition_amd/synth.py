@@ -40,9 +40,10 @@ MID = 2048
 N_CTRL = 5
 
 
-def buf_len_for(T):
-    """Capture-buffer length that holds a T-frame word (25 360 for T = 256)."""
-    return NOISE_LEN + LEAD_QUIET + HOP * (T - 1) + FRAME + TAIL_QUIET
+def buf_len_for(T, rate=1):
+    """Capture-buffer length that holds a T-frame word (25 360 for T = 256).  rate = 2: the 16 kHz extension
+    front end (every length doubles: 320/160 framing, 4800-sample noise head)."""
+    return rate * (NOISE_LEN + LEAD_QUIET + HOP * (T - 1) + FRAME + TAIL_QUIET)
 
 
 def word_bank(n_words, seed=1234):
@@ -54,7 +55,7 @@ def word_bank(n_words, seed=1234):
 
 
 def make_utterances(word_ids, frames, seed, bank, S=None, gain=1.0, head_sigma=8.0, quiet_sigma=4.0,
-                    speech_sigma=30.0, device="cpu", chunk=2048):
+                    speech_sigma=30.0, device="cpu", chunk=2048, rate=1):
     """uint16-valued capture buffers, returned as an int16 torch tensor view-compatible with u16 [B, S].
 
     word_ids: int64 [B]; frames: int64 [B] target frame counts (<= the T that S was sized for).
@@ -65,18 +66,19 @@ def make_utterances(word_ids, frames, seed, bank, S=None, gain=1.0, head_sigma=8
     frames = torch.as_tensor(frames, dtype=torch.int64)
     B = word_ids.numel()
     if S is None:
-        S = buf_len_for(int(frames.max()))
+        S = buf_len_for(int(frames.max()), rate)
+    hop, noise_len, fs = HOP * rate, NOISE_LEN * rate, FS * rate
     f_bank, a_bank = bank
     out = torch.empty(B, S, dtype=torch.int16, device=device)
     g = torch.Generator(device=device).manual_seed(seed)
     t = torch.arange(S, device=device, dtype=torch.float32)
-    p0 = NOISE_LEN + LEAD_QUIET + HOP
+    p0 = rate * (NOISE_LEN + LEAD_QUIET + HOP)
     for b0 in range(0, B, chunk):
         b1 = min(B, b0 + chunk)
         n = b1 - b0
         wid = word_ids[b0:b1]
         fr = frames[b0:b1].to(device=device, dtype=torch.float32)
-        span = (HOP * (fr - 1)).unsqueeze(1)                      # speech samples
+        span = (hop * (fr - 1)).unsqueeze(1)                      # speech samples
         u = ((t.unsqueeze(0) - p0) / span).clamp(0.0, 1.0)        # normalised time [n, S]
         in_word = (t.unsqueeze(0) >= p0) & (t.unsqueeze(0) < p0 + span)
         fc = f_bank[wid].to(device)                               # [n, 3, N_CTRL]
@@ -91,12 +93,12 @@ def make_utterances(word_ids, frames, seed, bank, S=None, gain=1.0, head_sigma=8
             f1 = torch.gather(fc[:, k, :], 1, i0 + 1)
             f = f0 + (f1 - f0) * w
             # phase = integral of f; float64 accumulate keeps the chirp clean over 20k samples
-            ph = torch.cumsum((f * in_word).to(torch.float64), dim=1) * (2 * math.pi / FS)
+            ph = torch.cumsum((f * in_word).to(torch.float64), dim=1) * (2 * math.pi / fs)
             sig += amp[:, k:k + 1] * torch.sin(ph.to(torch.float32) + ph0[:, k:k + 1])
         env = 0.55 + 0.45 * torch.sin(math.pi * u) ** 2           # floor keeps the word's edges loud
         noise = torch.randn(n, S, generator=g, device=device)
         sigma = torch.where(in_word, torch.tensor(speech_sigma, device=device),
-                            torch.where(t.unsqueeze(0) < NOISE_LEN, torch.tensor(head_sigma, device=device),
+                            torch.where(t.unsqueeze(0) < noise_len, torch.tensor(head_sigma, device=device),
                                         torch.tensor(quiet_sigma, device=device)))
         x = MID + torch.where(in_word, sig * env, torch.zeros_like(sig)) + noise * sigma
         out[b0:b1] = x.round().clamp(0, 4095).to(torch.int16)

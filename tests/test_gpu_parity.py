@@ -320,3 +320,47 @@ def test_dtw_dp_extension_matches_its_oracle():
     assert sc[0, 3] == 0
     assert (want == ol.DIS_ERR).sum() > 10 and (want != ol.DIS_ERR).sum() > 40
     eng.close()
+
+
+def test_extension_front_end_matches_its_oracle():
+    """EXTENSION (no reference counterpart): BASELINE configs[4] front end -- 16 kHz, 320/160 framing, 512-point
+    transform (2 x ST-style 256-point radix-4 + one radix-2 pass, oracle/q15_fft.c), 40 Mel, 12 MFCC.
+    Whole path (VAD, MFCC, greedy DTW, argmin) against the parametrised oracle."""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(16)
+    T, B, K, maxf = 100, 96, 12, 160
+    cfg = dict(fs=16000, nfft=512, n_mel=40)
+    orc = ol.Oracle(max_frames=maxf, **cfg)
+    bank = synth.word_bank(8)
+    tfr = [int(v) for v in rng.integers(70, 150, K)]
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(K) % 8, tfr, seed=21, bank=bank, rate=2,
+                                                  S=synth.buf_len_for(max(tfr), 2)))
+    tm = np.zeros((K, maxf + 1, 12), np.int16)
+    for k in range(K):
+        rc, a = orc.noise_atap(tp[k])
+        seg = orc.vad(tp[k], a)
+        n, m = orc.mfcc(tp[k], seg[0], seg[1], a)
+        assert n == tfr[k]
+        tm[k, :n] = m
+    tf = np.array(tfr, np.uint32)
+    pcm = synth.as_u16_numpy(synth.make_utterances(rng.integers(0, 8, B), [T] * B, seed=22, bank=bank, rate=2))
+    pcm[:6] = synth.as_u16_numpy(synth.make_utterances(rng.integers(0, 8, 6), [T - 10] * 6, seed=23, bank=bank, rate=2,
+                                                       S=pcm.shape[1], quiet_sigma=8.0, gain=3.0))
+    pcm[6] = 2048
+    eng = Engine(max_frames=maxf, device=0, **cfg)
+    eng.set_templates_dense(tm, tf)
+    out = eng.recognize(pcm)
+    tpl = orc.make_templates(tm, tf)
+    ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
+    for b in range(B):
+        rc, a = orc.noise_atap(pcm[b])
+        seg = orc.vad(pcm[b], a)
+        v = out["vad"][b]
+        assert (v["mid_val"], v["n_thl"], v["z_thl"], v["s_thl"]) == a.astuple(), b
+        assert np.array_equal(v["seg"], seg), b
+    assert np.array_equal(out["mfcc"], omf)
+    assert np.array_equal(out["scores"], osc)
+    for f in ("best_tpl", "min_dis", "frm_num", "status"):
+        assert np.array_equal(out["results"][f], ores[f]), f
+    assert (ores["frm_num"][7:] == T).all() and ores["status"][6] == ol.ST_VAD_FAIL
+    eng.close()
