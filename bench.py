@@ -52,7 +52,14 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="utterances timed on the host cores")
+    ap.add_argument("--workload", choices=["ref", "ext"], default="ref",
+                    help="ref = BASELINE configs[2] (the metric's config); ext = configs[4], the 16 kHz/512-pt/40-Mel x 500 "
+                         "templates EXTENSION (no reference counterpart; not the headline metric)")
     args = ap.parse_args()
+    global K, N_WORDS
+    rate, eng_cfg = 1, {}
+    if args.workload == "ext":
+        rate, eng_cfg, K, N_WORDS = 2, dict(fs=16000, nfft=512, n_mel=40), 500, 100
 
     rank, local_rank, world = du.env_rank()
     if world != args.gpus:
@@ -64,15 +71,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B = args.batch
-    S = synth.buf_len_for(T)
+    S = synth.buf_len_for(T, rate)
 
-    eng = Engine(max_frames=MAX_FRAMES, device=local_rank)
+    eng = Engine(max_frames=MAX_FRAMES, device=local_rank, **eng_cfg)
 
     # ---- templates: K synthetic words through the SAME front end (main.c:121-138 save_mdl) ----------
     bank = synth.word_bank(N_WORDS)
     rng = np.random.default_rng(2026)
     tfr = rng.integers(192, 321, K)
-    tpcm = synth.make_utterances(np.arange(K) % N_WORDS, tfr, seed=77, bank=bank, S=synth.buf_len_for(320), device=dev)
+    tpcm = synth.make_utterances(np.arange(K) % N_WORDS, tfr, seed=77, bank=bank, S=synth.buf_len_for(320, rate), device=dev,
+                                 rate=rate)
     tvad, tmf = eng.features_dev(tpcm)
     torch.cuda.synchronize()
     tv = vad_from_torch(tvad)
@@ -84,7 +92,7 @@ def main():
     # ---- this rank's shard of utterances, generated straight into HBM -------------------------------
     lo, hi = du.shard_bounds(world * B, world, rank)  # weak scaling: B utterances per rank
     words = torch.from_numpy(rng.integers(0, N_WORDS, world * B))[lo:hi]
-    pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev)
+    pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev, rate=rate)
     out = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
     gathered = torch.empty(world * B, K, dtype=torch.int32, device=dev) if world > 1 else None
 
@@ -121,7 +129,7 @@ def main():
         value = world * B * args.steps / dt
         C = 12
         by_path = algorithmic_bytes_per_utt(S, T, C, K)
-        by_mfcc = mfcc_kernel_bytes_per_utt(T, C)
+        by_mfcc = mfcc_kernel_bytes_per_utt(T, C) if rate == 1 else 2 * (160 * (T - 1) + 320 + 1) + 2 * T * C + 48
         ach = by_mfcc * B / (stage["mfcc"] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -131,7 +139,8 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "utterances/sec (256-frame, 100 templates)",
+            "metric": "utterances/sec (256-frame, 100 templates)" if args.workload == "ref"
+            else "utterances/sec (EXTENSION: 16 kHz/512-pt/40 Mel, 256-frame, 500 templates; no reference counterpart)",
             "value": value,
             "unit": "utterances/s",
             "n_gpus": world,
@@ -143,8 +152,9 @@ def main():
             "vs_baseline": None,
             "dtype": "s16/s32 fixed point (+ f32 sqrt)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: batch=65536 utterances x 100 templates per GPU, 256 frames, "
-                                   "12-coef MFCC, 8 kHz 25360-sample capture buffers",
+            "config": {"workload": ("BASELINE configs[2]: batch=65536 utterances x 100 templates per GPU, 256 frames, "
+                                    "12-coef MFCC, 8 kHz 25360-sample capture buffers") if args.workload == "ref" else
+                                   "BASELINE configs[4] EXTENSION: 16 kHz / 512-pt / 40 Mel, 256 frames x 500 templates",
                        "batch_per_gpu": B, "templates": K, "frames": T, "buf_len": S,
                        "parallelism": f"utterance-sharded x{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_mfcc", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -157,21 +167,21 @@ def main():
             "top1_word_accuracy": acc,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pcm, eng, out, tm, tfr, args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(pcm, eng, out, tm, tfr, args.cpu_sample, eng_cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(pcm, eng, out, tm, tfr, n):
+def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg):
     """The CPU restatement of the reference C path (oracle tier ii, validated against the reference's own
     objects) timed on this box's host cores over the first n utterances of the same batch; also used to
     cross-check the GPU results of those utterances."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     cores = os.cpu_count() or 1
-    orc = ol.Oracle(max_frames=MAX_FRAMES)
+    orc = ol.Oracle(max_frames=MAX_FRAMES, **eng_cfg)
     tpl = orc.make_templates(tm, tfr.astype(np.uint32))
     host = synth.as_u16_numpy(pcm[:n])
     orc.recognize_batch(host[:cores * 2], tpl, n_threads=cores, want_mfcc=False, want_scores=False)  # warm-up

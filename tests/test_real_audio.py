@@ -1,0 +1,82 @@
+"""Real speech through both oracle tiers (CPU, only where /root/reference exists).
+
+The reference ships 13 recordings (Matlab/语音样本/*.wav, 8 kHz, 8/16-bit) and three raw 12-bit ADC dumps.
+They are read in place (never copied into this repository), converted to the ADC-like 12-bit codes the
+firmware captures (ADC.C: 12-bit right-aligned, mid-scale ~2048) and pushed through
+noise_atap -> VAD -> get_mfcc -> dtw with the reference's own objects (tier i) and with the parametrised
+restatement (tier ii).  Everything must be bit-identical, which pins the restatement on real signals, not
+only on synthetic ones."""
+import glob
+import os
+import wave
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import REFERENCE, needs_reference
+from stm32_speech_recognition_amd import wavio
+
+SAMPLES = os.path.join(REFERENCE, "Matlab", "语音样本")
+
+
+def _captures():
+    """16 000-sample capture buffers cut from the reference's recordings: 2 400 samples of low-level noise
+    (the firmware records the room before the speaker starts, main.c:79-87) + 13 600 samples of audio."""
+    rng = np.random.default_rng(7)
+    out = []
+    for path in sorted(glob.glob(os.path.join(SAMPLES, "*.wav"))):
+        adc = wavio.wav_to_adc(path)
+        for off in range(0, max(1, len(adc) - 13600), 27200):
+            buf = np.empty(16000, dtype=np.uint16)
+            buf[:2400] = np.clip(np.round(2048 + rng.normal(0, 6, 2400)), 0, 4095)
+            chunk = adc[off:off + 13600]
+            buf[2400:2400 + len(chunk)] = chunk
+            buf[2400 + len(chunk):] = 2048
+            out.append(buf)
+            if len(out) >= 40:
+                return out
+    return out
+
+
+@needs_reference
+def test_wav_reader_handles_the_reference_recordings():
+    paths = sorted(glob.glob(os.path.join(SAMPLES, "*.wav")))
+    assert len(paths) >= 10
+    for p in paths:
+        with wave.open(p, "rb") as w:
+            assert w.getframerate() == 8000
+        adc = wavio.wav_to_adc(p)
+        assert adc.dtype == np.uint16 and adc.max() <= 4095 and len(adc) > 8000
+
+
+@needs_reference
+def test_real_speech_tier2_equals_tier1():
+    r = ol.RefLib()
+    o = ol.Oracle(max_frames=119)
+    caps = _captures()
+    assert len(caps) >= 20
+    feats, nseg = [], 0
+    for buf in caps:
+        a1, s1 = r.vad(buf)
+        rc, a2 = o.noise_atap(buf)
+        s2 = o.vad(buf, a2)
+        assert a1.astuple() == a2.astuple() and np.array_equal(s1, s2)
+        for k in range(3):
+            st, en = int(s1[2 * k]), int(s1[2 * k + 1])
+            if en < 0 or st < 1:
+                continue
+            nseg += 1
+            n1, m1, f1 = r.mfcc(buf, st, en, a1)
+            n2, m2 = o.mfcc(buf, st, en, a2)
+            assert n1 == n2 and np.array_equal(m1, m2)
+            if n1:
+                feats.append((n1, m1, f1))
+    assert nseg >= 15 and len(feats) >= 10
+    pad = np.zeros((2, 12), dtype=np.int16)
+    feats = feats[:24]
+    for i in range(len(feats)):
+        for j in range(len(feats)):
+            d1 = r.dtw(feats[i][2], feats[j][2])
+            d2 = o.dtw(np.concatenate([feats[i][1], pad]), feats[i][0], np.concatenate([feats[j][1], pad]), feats[j][0])
+            assert d1 == d2
