@@ -150,7 +150,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "s16/s32 fixed point (+ f32 sqrt)",
+            "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: batch=65536 utterances x 100 templates per GPU, 256 frames, "
                                     "12-coef MFCC, 8 kHz 25360-sample capture buffers") if args.workload == "ref" else

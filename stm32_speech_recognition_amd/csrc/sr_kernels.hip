@@ -1318,9 +1318,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
     if (in_n && mdl_n && !(in_n > mdl_n * 2 || 2 * in_n < mdl_n)) {  // main.c:283, DTW.C:133-137
         const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142
         const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
-        // dtw_limit (DTW.C:76-109) in the variables uu = y - 2x, ww = 2y - x of a point (x, y):
-        //   outside  <=>  (x < X1 ? uu >= 2 : ww >= t1)  ||  (x < X2 ? ww <= -2 : uu <= t2)
-        const int t1 = 4 - ((int)in_n - 2 * (int)mdl_n), t2 = ((int)mdl_n - 2 * (int)in_n) - 4;
+        const int c1s = 3 - ((int)in_n - 2 * (int)mdl_n), c2s = ((int)mdl_n - 2 * (int)in_n) - 3;
         // cursors: current input row in LDS, NEXT template row in HBM; rows px+1 / py+1 always exist inside the
         // loop (px+1 < in_n <= R and py+1 < mdl_n < tpl_rows; for 1-frame sequences row 1 is the slack row the
         // reference's do-while reads, DTW.C:150-154)
@@ -1336,7 +1334,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]);
             dis = dis_from(ci.w[6], cm.w[6], dot_rows(ci, cm));  // DTW.C:146
         }
-        int x = 1, y = 1, uu = -1, ww = 1;  // x = y = 1 (DTW.C:147-148)
+        int x = 1, y = 1;  // DTW.C:147-148
         uint32_t step = 1;
         do {
             const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]),
@@ -1345,12 +1343,16 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             const uint32_t d_up = dis_from(nm.w[6], ci.w[6], dot_rows(nm, ci));  // (x, y+1):   get_dis(mdl+12, in)
             const uint32_t d_rt = dis_from(cm.w[6], ni.w[6], dot_rows(cm, ni));  // (x+1, y):   get_dis(mdl, in+12)
             const uint32_t d_dg = dis_from(nm.w[6], ni.w[6], dot_rows(nm, ni));  // (x+1, y+1)
-            const bool xa1 = x < X1, xa2 = x < X2, xb1 = x + 1 < X1, xb2 = x + 1 < X2;
-            const bool o_up = (xa1 ? (uu + 1 >= 2) : (ww + 2 >= t1)) || (xa2 ? (ww + 2 <= -2) : (uu + 1 <= t2));
-            const bool o_rt = (xb1 ? (uu - 2 >= 2) : (ww - 1 >= t1)) || (xb2 ? (ww - 1 <= -2) : (uu - 2 <= t2));
-            const bool o_dg = (xb1 ? (uu - 1 >= 2) : (ww + 1 >= t1)) || (xb2 ? (ww + 1 <= -2) : (uu - 1 <= t2));
-            const uint32_t up = o_up ? SR_DIS_ERR : d_up, right = o_rt ? SR_DIS_ERR : d_rt,
-                           diag = o_dg ? SR_DIS_ERR : d_dg;
+            // dtw_limit (DTW.C:76-109) as an interval test per column: (x', y') is inside  <=>  lb(x') <= y' <= ub(x')
+            //   ub(x') = x' < X1 ? 2x'+1 : (x'+3-c1) >> 1      (negation of DTW.C:78-91; >> floors)
+            //   lb(x') = x' < X2 ? x' >> 1 : 2x'+c2-3           (negation of DTW.C:93-106)
+            const int xb = x + 1, y1 = y + 1;
+            const int ubA = (x < X1) ? 2 * x + 1 : ((x + c1s) >> 1), lbA = (x < X2) ? (x >> 1) : 2 * x + c2s;
+            const int ubB = (xb < X1) ? 2 * xb + 1 : ((xb + c1s) >> 1), lbB = (xb < X2) ? (xb >> 1) : 2 * xb + c2s;
+            // sign bit of (y'-lb) | (ub-y') is set exactly when the point is outside
+            const uint32_t up = (((y1 - lbA) | (ubA - y1)) < 0) ? SR_DIS_ERR : d_up;
+            const uint32_t right = (((y - lbB) | (ubB - y)) < 0) ? SR_DIS_ERR : d_rt;
+            const uint32_t diag = (((y1 - lbB) | (ubB - y1)) < 0) ? SR_DIS_ERR : d_dg;
             uint32_t mn = diag;  // DTW.C:156-164
             if (mn > right) mn = right;
             if (mn > up) mn = up;
@@ -1368,8 +1370,6 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 tp += t_stride;
                 nm = row_from(tp[0], tp[1]);
             }
-            uu = y - 2 * x;
-            ww = 2 * y - x;
             step = (step + 1) & 0xFFFF;
         } while (x < (int)in_n && y < (int)mdl_n);  // DTW.C:188
         score = dis / step;
