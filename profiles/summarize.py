@@ -27,7 +27,7 @@ def main():
                 out.append(f"{r['Name']},{r['Calls']},{r['AverageNs']},{r['MinNs']},{r['MaxNs']},{r['Percentage']}")
     out += ["", "# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <counters>), LAST full-batch launch",
             "kernel,counter,value"]
-    vals = {}
+    vals, durs = {}, {}
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         fs = glob.glob(os.path.join(d, "*counter_collection.csv"))
         if not fs:
@@ -35,16 +35,21 @@ def main():
         acc = collections.defaultdict(dict)
         for r in csv.DictReader(open(fs[0])):
             if r["Kernel_Name"].startswith("sr::"):
-                acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] = float(r["Counter_Value"])
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                acc[name][r["Counter_Name"]] = float(r["Counter_Value"])
+                durs[(name, r["Counter_Name"])] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])  # ns, this pass
         for k in acc:
             for c, v in sorted(acc[k].items()):
                 out.append(f"{k},{c},{v:.0f}")
                 vals[(k, c)] = v
     # derived: VALU issue utilisation = SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) * 4 / (SIMDs * kernel cycles)
-    out += ["", "# derived (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs)", "kernel,metric,value"]
+    out += ["", "# derived (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; every counter is normalised with the",
+            "# duration of ITS OWN pass and the shader clock = GRBM_GUI_ACTIVE/8 / duration of the GRBM pass)", "kernel,metric,value"]
     for k in ("sr::k_mfcc", "sr::k_dtw_lds", "sr::k_vad"):
         try:
-            cyc = vals[(k, "GRBM_GUI_ACTIVE")] / 8.0
+            clk = vals[(k, "GRBM_GUI_ACTIVE")] / 8.0 / durs[(k, "GRBM_GUI_ACTIVE")]  # cycles per ns
+            out.append(f"{k},shader_clock_ghz,{clk:.3f}")
+            cyc = clk * durs[(k, "SQ_ACTIVE_INST_VALU")]
             busy = vals[(k, "SQ_ACTIVE_INST_VALU")] * 4.0 / (1024.0 * cyc)
             out.append(f"{k},valu_busy_fraction,{busy:.3f}")
             out.append(f"{k},cycles_per_valu_inst,{vals[(k, 'SQ_ACTIVE_INST_VALU')] * 4.0 / vals[(k, 'SQ_INSTS_VALU')]:.2f}")

@@ -105,10 +105,11 @@ def _oracle_templates(orc, bank, frames, seed, S):
     return tm, np.array(frames, np.uint32)
 
 
-@pytest.mark.parametrize("T,B,K", [(256, 256, 100), (119, 512, 10)])
+@pytest.mark.parametrize("T,B,K", [(256, 1024, 100), (256, 4096, 10), (119, 512, 10)])
 def test_full_path_matches_oracle(T, B, K):
-    """BASELINE configs 2/3 shapes at a batch the oracle finishes in seconds: MFCC s16 exact,
-    all K scores u32 exact, argmin exact."""
+    """BASELINE configs[1] in full (4096 x 10, every utterance compared) and a 1024-utterance sample of
+    configs[2] (x 100 templates), 256 frames each, plus a reference-sized case: MFCC s16 exact, all K scores u32
+    exact, argmin exact (>= 1024 utterances per config)."""
     from stm32_speech_recognition_amd import Engine
     from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch
     rng = np.random.default_rng(T + B)
@@ -133,7 +134,7 @@ def test_full_path_matches_oracle(T, B, K):
     res = results_from_torch(out["results"])
     vd = vad_from_torch(out["vad"])
     tpl = orc.make_templates(tm, tf, valid)
-    ores, omf, osc = orc.recognize_batch(synth.as_u16_numpy(pcm_t), tpl, n_threads=8)
+    ores, omf, osc = orc.recognize_batch(synth.as_u16_numpy(pcm_t), tpl, n_threads=min(64, os.cpu_count() or 8))
     assert np.array_equal(vd["status"], ores["status"])
     assert np.array_equal(out["mfcc"].cpu().numpy(), omf)
     assert np.array_equal(out["scores"].cpu().numpy().view(np.uint32), osc)
