@@ -10,6 +10,12 @@
  * arithmetic is 32-bit two's complement (wraps), LDRSH sign-extends a 16-bit
  * half, STRH keeps the low 16 bits, ASR is an arithmetic (floor) shift.
  *
+ * PARITY STATUS of this file: the assembly itself cannot be executed here, so
+ * this restatement is "unpinned by execution".  Its evidence: the regenerated
+ * coefficient table equals the .s table entry for entry, the output agrees with
+ * an exact DFT/1024 within the truncation error of the five >>2 passes, and the
+ * structure follows the cited instruction groups one by one.
+ *
  * The coefficient table is regenerated from its closed form rather than
  * pasted; tests/test_oracle_tables.py parses the table out of the .s file
  * (when /root/reference is present) and requires 0 mismatches.

@@ -365,3 +365,83 @@ def test_extension_front_end_matches_its_oracle():
         assert np.array_equal(out["results"][f], ores[f]), f
     assert (ores["frm_num"][7:] == T).all() and ores["status"][6] == ol.ST_VAD_FAIL
     eng.close()
+
+
+def test_dtw_generic_fallback_matches_oracle():
+    """sequences too long for the LDS-staged kernel (max_frames = 6000) and more than 1024 templates go through
+    the generic global-memory walk k_dtw: same arithmetic, must give the same scores"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(5)
+    # (a) huge frame cap, realistic lengths
+    maxf, K, B = 6000, 7, 9
+    orc = ol.Oracle(max_frames=maxf)
+    tf = np.array([50, 900, 1500, 2999, 3000, 5999, 6000], np.uint32)
+    tm = rng.integers(-2000, 2000, (K, maxf + 1, 12)).astype(np.int16)
+    inf = np.array([60, 1000, 1499, 3000, 4000, 6000, 1, 2, 2500], np.uint32)
+    im = rng.integers(-2000, 2000, (B, maxf, 12)).astype(np.int16)
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf)
+    sc, res = eng.dtw(im, inf)
+    pad = np.zeros((1, 12), np.int16)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
+                    dtype=np.uint32)
+    assert np.array_equal(sc, want)
+    assert (want != ol.DIS_ERR).sum() >= 15
+    eng.close()
+    # (b) more templates than one workgroup can hold
+    maxf, K, B = 40, 1100, 3
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(10, 41, K).astype(np.uint32)
+    tm = rng.integers(-2000, 2000, (K, maxf + 1, 12)).astype(np.int16)
+    inf = np.array([20, 30, 40], np.uint32)
+    im = rng.integers(-2000, 2000, (B, maxf, 12)).astype(np.int16)
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf)
+    sc, res = eng.dtw(im, inf)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
+                    dtype=np.uint32)
+    assert np.array_equal(sc, want)
+    assert np.array_equal(res["min_dis"], want.min(1))
+    eng.close()
+
+
+def test_argument_checks_and_edge_sizes(golden):
+    """error behaviour of the batched API: no templates, bad alignment / stride, short buffers, empty batch;
+    and the largest capture buffer the reference's u16 length allows (65 528 samples)"""
+    import ctypes as C
+    from stm32_speech_recognition_amd import Engine, SrError
+    from stm32_speech_recognition_amd.engine import _vp
+    e = Engine(max_frames=119, device=0)
+    pcm = golden["pcm"]
+    with pytest.raises(SrError, match="no templates"):
+        e.recognize(pcm)
+    e.set_templates_store(golden["store"])
+    with pytest.raises(SrError, match="noise head|shorter"):
+        e.recognize(pcm[:, :2000])
+    assert e.recognize(pcm[:0])["results"].shape == (0,)  # empty batch is a no-op
+    # device API: misaligned pointer / stride not a multiple of 8
+    t = torch.zeros(2 * 16008 + 8, dtype=torch.int16, device="cuda:0")
+    res = torch.zeros(2, 4, dtype=torch.int32, device="cuda:0")
+    rc = e.L.sr_recognize_batch_dev(e.h, C.c_void_p(t.data_ptr() + 2), C.c_uint64(16008), C.c_uint32(16000), C.c_uint32(2),
+                                    _vp(res), None, None, None, None)
+    assert rc == 3
+    rc = e.L.sr_recognize_batch_dev(e.h, C.c_void_p(t.data_ptr()), C.c_uint64(16004), C.c_uint32(16000), C.c_uint32(2),
+                                    _vp(res), None, None, None, None)
+    assert rc == 3
+    # ragged: buf_len shorter than the row stride is fine
+    out = e.recognize(np.concatenate([pcm, np.zeros((pcm.shape[0], 40), np.uint16)], 1), buf_len=16000)
+    assert np.array_equal(out["results"]["min_dis"], golden["recg_dis"])
+    e.close()
+    # maximum buffer: VAD(const u16 *vc, u16 buf_len, ...) -> 65 535 samples at most; 65 528 keeps rows 16-byte multiples
+    o = ol.Oracle(max_frames=119)
+    big = np.full((2, 65528), 2048, np.uint16)
+    rng = np.random.default_rng(1)
+    big[:] = np.clip(2048 + rng.normal(0, 5, big.shape), 0, 4095).astype(np.uint16)
+    big[:, :16000] = pcm[:2]
+    big[1, 60000:63000] = pcm[3, 3000:6000]  # a late second burst
+    e2 = Engine(max_frames=119, device=0)
+    vd = e2.vad(big)
+    for b in range(2):
+        rc_, a = o.noise_atap(big[b])
+        assert np.array_equal(vd["seg"][b], o.vad(big[b], a))
+    e2.close()
