@@ -18,6 +18,8 @@ struct DevTables {
     const uint32_t *tw_a;      // [1020]
     const uint32_t *tw_b;      // [1020]
     const uint32_t *log_thr;   // [2220]
+    const uint32_t *tri_even32;  // [bins] the same weights widened to 32 bits (16-byte vector loads in k_mfcc)
+    const uint32_t *tri_odd32;
     const uint32_t *w512_a;    // [256]  EXTENSION front end only
     const uint32_t *w512_b;    // [256]
 };

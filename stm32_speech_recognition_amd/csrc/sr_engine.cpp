@@ -156,15 +156,17 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     build_tables(h->host, fe);
     // one blob, 16-byte aligned sub-tables
     const HostTables &t = h->host;
+    std::vector<uint32_t> te32(t.tri_even.begin(), t.tri_even.end()), to32(t.tri_odd.begin(), t.tri_odd.end());
     struct Part {
         const void *src;
         size_t bytes;
         size_t off;
-    } parts[10] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
+    } parts[12] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
                   {t.tri_odd.data(), t.tri_odd.size() * 2, 0}, {t.tri_cen.data(), t.tri_cen.size() * 2, 0},
                   {t.dct.data(), t.dct.size(), 0},             {t.tw_a.data(), t.tw_a.size() * 4, 0},
                   {t.tw_b.data(), t.tw_b.size() * 4, 0},       {t.log_thr.data(), t.log_thr.size() * 4, 0},
-                  {t.w512_a.data(), t.w512_a.size() * 4, 0},   {t.w512_b.data(), t.w512_b.size() * 4, 0}};
+                  {t.w512_a.data(), t.w512_a.size() * 4, 0},   {t.w512_b.data(), t.w512_b.size() * 4, 0},
+                  {te32.data(), te32.size() * 4, 0},           {to32.data(), to32.size() * 4, 0}};
     size_t total = 0;
     for (auto &p : parts) {
         p.off = total;
@@ -189,6 +191,8 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->dev.log_thr = (const uint32_t *)(base + parts[7].off);
     h->dev.w512_a = (const uint32_t *)(base + parts[8].off);
     h->dev.w512_b = (const uint32_t *)(base + parts[9].off);
+    h->dev.tri_even32 = (const uint32_t *)(base + parts[10].off);
+    h->dev.tri_odd32 = (const uint32_t *)(base + parts[11].off);
     *out = h;
     return SR_OK;
 }

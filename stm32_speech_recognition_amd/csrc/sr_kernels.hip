@@ -299,6 +299,20 @@ __device__ __forceinline__ void load_tw24(const u32x4 *lds, int lane, uint32_t (
     }
 }
 
+// pass-3 coefficients depend on (d0, d1) only: 4 x 24 words, read with lane-broadcast by d0 = lane & 3
+__device__ __forceinline__ void load_tw24_d0(const u32x4 *lds, int d0, uint32_t (&k)[4][3][2])
+{
+    uint32_t *f = &k[0][0][0];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const u32x4 q = lds[d0 * 6 + c];
+        f[4 * c] = q.x;
+        f[4 * c + 1] = q.y;
+        f[4 * c + 2] = q.z;
+        f[4 * c + 3] = q.w;
+    }
+}
+
 // Passes 1-3 for the zero-padded real frame that get_mfcc feeds (MFCC.C:37-47): only x[0..159] are
 // non-zero and every imaginary part is 0.  Pass 1 (.s:226-232) then degenerates exactly to
 // out[4*idx+k] = x[bitrev8(idx)] >> 2 (k = 0..3), so it is folded into the gather.
@@ -333,7 +347,7 @@ __device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const
     }
     // pass-3 coefficients (24 words per lane) are parked in LDS, shared by the workgroup's waves
     uint32_t k3[4][3][2];
-    load_tw24(tw3_lds, lane, k3);
+    load_tw24_d0(tw3_lds, lane & 3, k3);
 #pragma unroll
     for (int d1 = 0; d1 < 4; d1++)
         bfly(v[d1][0], v[d1][1], v[d1][2], v[d1][3], k3[d1][0][0], k3[d1][0][1], k3[d1][1][0], k3[d1][1][1],
@@ -363,7 +377,7 @@ constexpr int kMfccWaves = 4;       // waves per workgroup
 constexpr int kFramesPerWave = 16;   // consecutive frames one wave turns into MFCCs per work item
 constexpr int kFramesPerTile = kMfccWaves * kFramesPerWave;
 // per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
-constexpr int kWaveLdsWords = kXchgWords + kFrameLen + kFramesPerWave * kMel;
+constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMel;  // the windowed frame aliases the exchange area
 
 // (u32)(log((double)n)*100), MFCC.C:168, as a step function (see sr_tables.cpp gen_log_thr).
 __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__restrict__ thr)
@@ -381,15 +395,15 @@ __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__res
     return (uint32_t)m;
 }
 
-__global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
+__global__ void __launch_bounds__(64 * kMfccWaves, 5) k_mfcc(const MfccArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ int8_t s_dct[kCoef * kMel];
-    __shared__ u32x4 s_tw3[6 * 64], s_tw5[6 * 64];  // pass-3 / pass-5 coefficients of every lane (same for all waves)
+    __shared__ u32x4 s_tw3[6 * 4], s_tw5[6 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
-    int *xw = (int *)(buf + kXchgWords);
-    uint32_t *powb = buf + kXchgWords + kFrameLen;
+    int *xw = (int *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
+    uint32_t *powb = buf + kXchgWords;
 
     for (int i = threadIdx.x; i < kCoef * kMel; i += blockDim.x) s_dct[i] = a.t.dct[i];
     __syncthreads();
@@ -397,18 +411,18 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     // ---- lane-invariant constants --------------------------------------------------------------
     LaneTw tw;
     load_lane_tw(a.t, lane, tw);
-    if (w == 0) store_tw24(s_tw3, lane, tw.s3);
+    if (w == 0 && lane < 4) {
+        const uint32_t *f = &tw.s3[0][0][0];
+#pragma unroll
+        for (int c = 0; c < 6; c++) s_tw3[lane * 6 + c] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+    }
     if (w == 1 % kMfccWaves) store_tw24(s_tw5, lane, tw.s5);
     __syncthreads();
     int hamm_r[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
-    uint32_t tri_e[8], tri_o[8];  // triangle weights of bins 8*lane .. 8*lane+7
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        tri_e[k] = a.t.tri_even[8 * lane + k];
-        tri_o[k] = a.t.tri_odd[8 * lane + k];
-    }
+    // triangle weights of bins 8*lane .. 8*lane+7 are re-read (L1-resident) per frame to keep registers free
+    const u32x4 *tri_e_p = (const u32x4 *)(a.t.tri_even32 + 8 * lane), *tri_o_p = (const u32x4 *)(a.t.tri_odd32 + 8 * lane);
     // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
     int f_lo = 0, f_hi = 0;
     if (lane < kMel) {
@@ -510,6 +524,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             {
                 const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
                 const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const u32x4 te0 = tri_e_p[0], te1 = tri_e_p[1], to0 = tri_o_p[0], to1 = tri_o_p[1];
+                const uint32_t tri_e[8] = {te0.x, te0.y, te0.z, te0.w, te1.x, te1.y, te1.z, te1.w};
+                const uint32_t tri_o[8] = {to0.x, to0.y, to0.z, to0.w, to1.x, to1.y, to1.z, to1.w};
                 uint32_t se = 0, so = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
