@@ -172,6 +172,10 @@ int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
 
+/* diagnostics: the path's non-integer device functions swept directly:
+ * out[3i] = (u32)(log((double)x)*100) (MFCC.C:168), out[3i+1] = (u32)sqrtf((float)x) (DTW.C:59),
+ * out[3i+2] = (u32)(sqrtf((float)(s32)(x & 0x7fffffff))*10) (MFCC.C:56-58) */
+int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
 /* diagnostics: per-utterance ballots of the VAD "loud" decision (VAD.C:164), 63 frames per 64-bit word, 16 words */
 int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                        sr_vad_rec *vad, uint64_t *masks);

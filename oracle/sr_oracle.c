@@ -419,6 +419,18 @@ uint32_t sr_oracle_dtw(const int16_t *in, uint32_t in_n, const int16_t *mdl, uin
     return dis / step;
 }
 
+/* the three non-integer expressions of the path on their own (same C expressions as MFCC.C:168, DTW.C:59, MFCC.C:56-58) */
+void sr_oracle_math_diag(const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t x = in[i];
+        int32_t r = (int32_t)(x & 0x7FFFFFFFu);
+        out[3 * i + 0] = x ? (uint32_t)(log((double)x) * 100) : 0u;
+        out[3 * i + 1] = (uint32_t)sqrtf((float)x);
+        out[3 * i + 2] = (uint32_t)(sqrtf((float)r) * 10);
+    }
+}
+
 /* ---- NON-REFERENCE extension: full dynamic-programming DTW ---------------
  * Own definition (no reference counterpart; the reference's dtw() is the greedy walk above):
  *   cells (x,y), 1-based, allowed iff dtw_limit(x,y) == ins (DTW.C:76-109) with the pair's X1/X2;

@@ -88,6 +88,8 @@ void launch_fft_q15(const uint32_t *in, uint32_t *out, uint32_t n, const DevTabl
 // frames: [n][160] int16; mag: [n][512]; also writes raw FFT words of bins 512..1023 to raw_hi if non-null
 void launch_fft_mag(const int16_t *frames, uint32_t len, uint32_t *mag, uint32_t *raw_hi, uint32_t n,
                     const DevTables &t, hipStream_t s);
+// diagnostics: log / sqrt device functions swept directly (see k_math_diag)
+void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
 // get_dis (DTW.C:45-62) for n frame pairs
 void launch_get_dis(const int16_t *a, const int16_t *b, uint32_t *out, uint32_t n, hipStream_t s);
 // dtw_limit (DTW.C:76-109) for n points with explicit statics

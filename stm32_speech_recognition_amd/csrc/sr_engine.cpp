@@ -771,6 +771,22 @@ int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_fra
     return SR_OK;
 }
 
+// diagnostics: out[3*i + {0,1,2}] = (u32)(log(x)*100), (u32)sqrtf(x), (u32)(sqrtf((s32)x)*10) as the kernels compute them
+int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    if (!h || !in || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (n == 0) return SR_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->s_u32a.reserve(n))) return rc;
+    if ((rc = h->s_u32b.reserve((size_t)3 * n))) return rc;
+    HIP_TRY(hipMemcpy(h->s_u32a.p, in, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_math_diag(h->s_u32a.p, h->s_u32b.p, n, h->dev, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, h->s_u32b.p, (size_t)3 * n * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
 {
     if (!h || !in || !out) return fail(SR_ERR_BAD_ARG, "null argument");

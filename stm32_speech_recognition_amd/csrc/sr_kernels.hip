@@ -1585,6 +1585,27 @@ void launch_dtw_dp(const DtwArgs &a, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// diagnostics: the three non-integer device functions on their own, so tests can sweep them directly
+//   out[3i+0] = (u32)(log((double)x)*100)                       MFCC.C:168   (step-function evaluation)
+//   out[3i+1] = (u32)sqrtf((float)x)                            DTW.C:59     (v_sqrt_f32 + fused-residual correction)
+//   out[3i+2] = (u32)(sqrtf((float)(s32)x)*10), x < 2^31        MFCC.C:56-58
+// ------------------------------------------------------------------------------------------------
+__global__ void k_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *log_thr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = in[i];
+    out[3 * i + 0] = log100_u32(x, log_thr);
+    out[3 * i + 1] = (uint32_t)sqrt_rn_int((float)x);
+    out[3 * i + 2] = (uint32_t)(sqrt_rn_int((float)(int)(x & 0x7FFFFFFFu)) * 10.0f);
+}
+void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_math_diag, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, t.log_thr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // scalar helpers of DTW.C exposed by the reference-compatible symbols
 // ------------------------------------------------------------------------------------------------
 __global__ void k_get_dis(const int16_t *pa, const int16_t *pb, uint32_t *out, uint32_t n)

@@ -445,3 +445,30 @@ def test_argument_checks_and_edge_sizes(golden):
         rc_, a = o.noise_atap(big[b])
         assert np.array_equal(vd["seg"][b], o.vad(big[b], a))
     e2.close()
+
+
+def test_log_and_sqrt_device_functions_swept_directly(eng119):
+    """(u32)(log(x)*100), (u32)sqrtf(x) and (u32)(sqrtf(r)*10) as the kernels compute them, against the same C
+    expressions on the host: every step position of the log table +-1, perfect squares +-1 over the whole u32
+    range (incl. the float-rounding regime >= 2^24), powers of two, and 2 M random values"""
+    import ctypes as C
+    from stm32_speech_recognition_amd.engine import _vp
+    orc = ol.Oracle()
+    rng = np.random.default_rng(99)
+    k = np.arange(0, 65536, dtype=np.uint64)
+    sq = (k * k).astype(np.uint64)
+    cand = [np.array([0, 1, 2, 3, 0xFFFFFFFF, 0xFFFFFFFE, 0x7FFFFFFF, 0x80000000], np.uint64), sq, sq + 1, sq[1:] - 1,
+            (np.uint64(1) << np.arange(32, dtype=np.uint64)), (np.uint64(1) << np.arange(1, 32, dtype=np.uint64)) - 1,
+            rng.integers(0, 1 << 32, 1_000_000, dtype=np.uint64), rng.integers(0, 1 << 24, 500_000, dtype=np.uint64),
+            (rng.integers(0, 65536, 500_000, dtype=np.uint64) ** 2 + rng.integers(-300, 300, 500_000)).clip(0, 0xFFFFFFFF)]
+    # step positions of floor(100 ln n): n = ceil(exp(m/100)) and neighbours
+    m = np.arange(0, 2219)
+    th = np.ceil(np.exp(m / 100.0)).astype(np.uint64).clip(1, 0xFFFFFFFF)
+    cand += [th, (th - 1).clip(0, None), (th + 1).clip(None, 0xFFFFFFFF)]
+    x = np.concatenate([c.astype(np.uint64) for c in cand]).clip(0, 0xFFFFFFFF).astype(np.uint32)
+    got = np.zeros(3 * len(x), np.uint32)
+    want = np.zeros(3 * len(x), np.uint32)
+    assert eng119.L.sr_math_diag(eng119.h, _vp(x), _vp(got), C.c_uint32(len(x))) == 0
+    orc.L.sr_oracle_math_diag(x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), C.c_uint32(len(x)))
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (x[bad[:5] // 3], bad[:5] % 3, got[bad[:5]], want[bad[:5]])
