@@ -431,6 +431,34 @@ void sr_oracle_math_diag(const uint32_t *in, uint32_t *out, uint32_t n)
     }
 }
 
+typedef struct {
+    const uint32_t *in;
+    uint32_t *out;
+    uint32_t n;
+} diag_job;
+static void *diag_worker(void *arg)
+{
+    diag_job *j = arg;
+    sr_oracle_math_diag(j->in, j->out, j->n);
+    return NULL;
+}
+/* same, split over n_threads host threads (used by the exhaustive 2^32 sweep) */
+void sr_oracle_math_diag_mt(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t n_threads)
+{
+    pthread_t th[512];
+    diag_job jobs[512];
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 512) n_threads = 512;
+    for (uint32_t t = 0; t < n_threads; t++) {
+        uint32_t lo = (uint32_t)((uint64_t)n * t / n_threads), hi = (uint32_t)((uint64_t)n * (t + 1) / n_threads);
+        jobs[t].in = in + lo;
+        jobs[t].out = out + (size_t)3 * lo;
+        jobs[t].n = hi - lo;
+        pthread_create(&th[t], NULL, diag_worker, &jobs[t]);
+    }
+    for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+}
+
 /* ---- NON-REFERENCE extension: full dynamic-programming DTW ---------------
  * Own definition (no reference counterpart; the reference's dtw() is the greedy walk above):
  *   cells (x,y), 1-based, allowed iff dtw_limit(x,y) == ins (DTW.C:76-109) with the pair's X1/X2;
