@@ -37,6 +37,14 @@ __device__ __forceinline__ int sdot2z(uint32_t a, uint32_t b)
     asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// a.lo*b.lo + a.hi*b.hi + c with a separate destination (VOP3P): C+D and C-D of the butterfly come straight out
+// of the multiplier when the third leg's coefficient is also kept negated
+__device__ __forceinline__ int sdot2a(uint32_t a, uint32_t b, int c)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // full-rate 24-bit multiplies where the operands provably fit (quarter-rate v_mul_lo_u32 otherwise)
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
@@ -217,19 +225,24 @@ __device__ __forceinline__ void r4_packed(uint32_t x0_in, int br, int bi, int sr
 
 template <bool HALF>  // HALF: only x0, x1 are produced (last pass: bins >= 512 are never read, MFCC.C:49)
 __device__ __forceinline__ void bfly_pk(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, uint32_t k1a,
-                                        uint32_t k1b, uint32_t k2a, uint32_t k2b, uint32_t k3a, uint32_t k3b)
+                                        uint32_t k1b, uint32_t k2a, uint32_t k2b, uint32_t k3a, uint32_t k3b,
+                                        uint32_t k3na, uint32_t k3nb)
 {
-    int br, bi, cr, ci, dr, di;
-    cxmul(x3, k3a, k3b, dr, di);
+    int br, bi, cr, ci;
     cxmul(x2, k2a, k2b, cr, ci);
     cxmul(x1, k1a, k1b, br, bi);
-    r4_packed<HALF, true>(x0, br, bi, cr + dr, ci + di, cr - dr, ci - di, x0, x1, x2, x3);
+    // C' = C + D and D' = C - D without ever forming D: D = x3*conj(K3) is accumulated onto C with K3 and -K3
+    const int sr = sdot2a(x3, k3a, cr), si = sdot2a(x3, k3b, ci);
+    const int tr = sdot2a(x3, k3na, cr), ti = sdot2a(x3, k3nb, ci);
+    r4_packed<HALF, true>(x0, br, bi, sr, si, tr, ti, x0, x1, x2, x3);
 }
+
+__device__ __forceinline__ uint32_t pk_neg(uint32_t w) { return pk_sub(0u, w); }
 
 __device__ __forceinline__ void bfly(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, uint32_t k1a, uint32_t k1b,
                                      uint32_t k2a, uint32_t k2b, uint32_t k3a, uint32_t k3b)
 {
-    bfly_pk<false>(x0, x1, x2, x3, k1a, k1b, k2a, k2b, k3a, k3b);
+    bfly_pk<false>(x0, x1, x2, x3, k1a, k1b, k2a, k2b, k3a, k3b, pk_neg(k3a), pk_neg(k3b));  // generic paths: negate on the fly
 }
 
 __device__ __forceinline__ int rev2(int d) { return ((d & 1) << 1) | (d >> 1); }
@@ -243,9 +256,9 @@ constexpr int kXchgWords = 1024 + 4 * 16;  // 1088
 // Coefficients a lane needs, all lane-invariant across frames -> loaded once per wave into VGPRs.
 struct LaneTw {
     uint32_t s2[2][2];     // pass 2 (q=4):   legs j+q, j+2q (j+3q is always zero-padding)
-    uint32_t s3[4][3][2];  // pass 3 (q=16):  per d1, legs j+q, j+2q, j+3q
-    uint32_t s4[3][2];     // pass 4 (q=64)
-    uint32_t s5[4][3][2];  // pass 5 (q=256): per d3
+    uint32_t s3[4][4][2];  // pass 3 (q=16):  per d1, legs j+q, j+2q, j+3q, and the j+3q pair negated
+    uint32_t s4[4][2];     // pass 4 (q=64)
+    uint32_t s5[4][4][2];  // pass 5 (q=256): per d3
 };
 
 // Table entry order per butterfly is (leg j+3q, leg j+2q, leg j+q)  (.s:182-191).
@@ -260,6 +273,20 @@ __device__ __forceinline__ void load_tw3(const DevTables &t, int base, int b, ui
     k[2][1] = t.tw_b[e + 0];  // leg j+3q
 }
 
+// legs j+q, j+2q, j+3q as above + entry [3] = the j+3q pair negated (for C+D / C-D by accumulation)
+__device__ __forceinline__ void load_tw4(const DevTables &t, int base, int b, uint32_t (&k)[4][2])
+{
+    uint32_t k3[3][2];
+    load_tw3(t, base, b, k3);
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        k[e][0] = k3[e][0];
+        k[e][1] = k3[e][1];
+    }
+    k[3][0] = pk_sub(0u, k3[2][0]);
+    k[3][1] = pk_sub(0u, k3[2][1]);
+}
+
 __device__ __forceinline__ void load_lane_tw(const DevTables &t, int lane, LaneTw &tw)
 {
     const int d0 = lane & 3;
@@ -272,25 +299,26 @@ __device__ __forceinline__ void load_lane_tw(const DevTables &t, int lane, LaneT
         tw.s2[1][1] = k[1][1];
     }
 #pragma unroll
-    for (int d1 = 0; d1 < 4; d1++) load_tw3(t, 12, d0 + 4 * d1, tw.s3[d1]);
-    load_tw3(t, 60, lane, tw.s4);
+    for (int d1 = 0; d1 < 4; d1++) load_tw4(t, 12, d0 + 4 * d1, tw.s3[d1]);
+    load_tw4(t, 60, lane, tw.s4);
 #pragma unroll
-    for (int d3 = 0; d3 < 4; d3++) load_tw3(t, 252, lane + 64 * d3, tw.s5[d3]);
+    for (int d3 = 0; d3 < 4; d3++) load_tw4(t, 252, lane + 64 * d3, tw.s5[d3]);
 }
 
-// 24 lane-invariant coefficient words parked in LDS as 6 x 16-byte chunks, chunk c of lane l at [c*64 + l]
-// (consecutive lanes -> consecutive 16-byte slots: conflict-free ds_read_b128 / ds_write_b128)
-__device__ __forceinline__ void store_tw24(u32x4 *lds, int lane, const uint32_t (&k)[4][3][2])
+// 32 lane-invariant coefficient words (4 entries x 2 words per butterfly, 4 butterflies) parked in LDS as
+// 8 x 16-byte chunks, chunk c of lane l at [c*64 + l] (consecutive lanes -> consecutive 16-byte slots:
+// conflict-free ds_read_b128 / ds_write_b128)
+__device__ __forceinline__ void store_tw32(u32x4 *lds, int lane, const uint32_t (&k)[4][4][2])
 {
     const uint32_t *f = &k[0][0][0];
 #pragma unroll
-    for (int c = 0; c < 6; c++) lds[c * 64 + lane] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+    for (int c = 0; c < 8; c++) lds[c * 64 + lane] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
 }
-__device__ __forceinline__ void load_tw24(const u32x4 *lds, int lane, uint32_t (&k)[4][3][2])
+__device__ __forceinline__ void load_tw32(const u32x4 *lds, int lane, uint32_t (&k)[4][4][2])
 {
     uint32_t *f = &k[0][0][0];
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
+    for (int c = 0; c < 8; c++) {
         const u32x4 q = lds[c * 64 + lane];
         f[4 * c] = q.x;
         f[4 * c + 1] = q.y;
@@ -298,14 +326,13 @@ __device__ __forceinline__ void load_tw24(const u32x4 *lds, int lane, uint32_t (
         f[4 * c + 3] = q.w;
     }
 }
-
-// pass-3 coefficients depend on (d0, d1) only: 4 x 24 words, read with lane-broadcast by d0 = lane & 3
-__device__ __forceinline__ void load_tw24_d0(const u32x4 *lds, int d0, uint32_t (&k)[4][3][2])
+// pass-3 coefficients depend on (d0, d1) only: 4 x 32 words, read with lane-broadcast by d0 = lane & 3
+__device__ __forceinline__ void load_tw32_d0(const u32x4 *lds, int d0, uint32_t (&k)[4][4][2])
 {
     uint32_t *f = &k[0][0][0];
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
-        const u32x4 q = lds[d0 * 6 + c];
+    for (int c = 0; c < 8; c++) {
+        const u32x4 q = lds[d0 * 8 + c];
         f[4 * c] = q.x;
         f[4 * c + 1] = q.y;
         f[4 * c + 2] = q.z;
@@ -346,12 +373,12 @@ __device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const
         }
     }
     // pass-3 coefficients (24 words per lane) are parked in LDS, shared by the workgroup's waves
-    uint32_t k3[4][3][2];
-    load_tw24_d0(tw3_lds, lane & 3, k3);
+    uint32_t k3[4][4][2];
+    load_tw32_d0(tw3_lds, lane & 3, k3);
 #pragma unroll
     for (int d1 = 0; d1 < 4; d1++)
-        bfly(v[d1][0], v[d1][1], v[d1][2], v[d1][3], k3[d1][0][0], k3[d1][0][1], k3[d1][1][0], k3[d1][1][1],
-             k3[d1][2][0], k3[d1][2][1]);
+        bfly_pk<false>(v[d1][0], v[d1][1], v[d1][2], v[d1][3], k3[d1][0][0], k3[d1][0][1], k3[d1][1][0], k3[d1][1][1],
+                       k3[d1][2][0], k3[d1][2][1], k3[d1][3][0], k3[d1][3][1]);
 }
 
 // lane (d0,d3,d4) -> LDS -> lane' = j & 63 holding u[d3][d4]
@@ -395,11 +422,11 @@ __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__res
     return (uint32_t)m;
 }
 
-__global__ void __launch_bounds__(64 * kMfccWaves, 5) k_mfcc(const MfccArgs a)
+__global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ int8_t s_dct[kCoef * kMel];
-    __shared__ u32x4 s_tw3[6 * 4], s_tw5[6 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
+    __shared__ u32x4 s_tw3[8 * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
     int *xw = (int *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
@@ -414,9 +441,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 5) k_mfcc(const MfccArgs a)
     if (w == 0 && lane < 4) {
         const uint32_t *f = &tw.s3[0][0][0];
 #pragma unroll
-        for (int c = 0; c < 6; c++) s_tw3[lane * 6 + c] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+        for (int c = 0; c < 8; c++) s_tw3[lane * 8 + c] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
     }
-    if (w == 1 % kMfccWaves) store_tw24(s_tw5, lane, tw.s5);
+    if (w == 1 % kMfccWaves) store_tw32(s_tw5, lane, tw.s5);
     __syncthreads();
     int hamm_r[3];
 #pragma unroll
@@ -499,16 +526,16 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 5) k_mfcc(const MfccArgs a)
             fft_exchange(buf, lane, v, u);
 #pragma unroll
             for (int e4 = 0; e4 < 4; e4++)
-                bfly(u[0][e4], u[1][e4], u[2][e4], u[3][e4], tw.s4[0][0], tw.s4[0][1], tw.s4[1][0], tw.s4[1][1],
-                     tw.s4[2][0], tw.s4[2][1]);
+                bfly_pk<false>(u[0][e4], u[1][e4], u[2][e4], u[3][e4], tw.s4[0][0], tw.s4[0][1], tw.s4[1][0], tw.s4[1][1],
+                               tw.s4[2][0], tw.s4[2][1], tw.s4[3][0], tw.s4[3][1]);
             // pass 5: only x[j] and x[j+q] (bins < 512) are consumed (MFCC.C:49)
             wave_sync();
-            uint32_t k5[4][3][2];
-            load_tw24(s_tw5, lane, k5);
+            uint32_t k5[4][4][2];
+            load_tw32(s_tw5, lane, k5);
 #pragma unroll
             for (int e3 = 0; e3 < 4; e3++) {
                 bfly_pk<true>(u[e3][0], u[e3][1], u[e3][2], u[e3][3], k5[e3][0][0], k5[e3][0][1], k5[e3][1][0],
-                              k5[e3][1][1], k5[e3][2][0], k5[e3][2][1]);
+                              k5[e3][1][1], k5[e3][2][0], k5[e3][2][1], k5[e3][3][0], k5[e3][3][1]);
                 // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
