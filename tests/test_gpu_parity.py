@@ -472,3 +472,23 @@ def test_log_and_sqrt_device_functions_swept_directly(eng119):
     orc.L.sr_oracle_math_diag(x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), C.c_uint32(len(x)))
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (x[bad[:5] // 3], bad[:5] % 3, got[bad[:5]], want[bad[:5]])
+
+
+def test_c_demo_reference_call_pattern(golden, tmp_path):
+    """plain-C program using the reference's own call sequence (noise_atap, VAD, get_mfcc, dtw per slot), the
+    spch_recg drop-in and the batched API: all three must agree with each other and with the golden fixture"""
+    import subprocess
+    from test_abi_symbols import build_c_demo
+    exe = str(tmp_path / "spch_recg_demo")
+    build_c_demo(exe)
+    golden["store"].tofile(str(tmp_path / "store.bin"))
+    for b in (0, 3, 9):
+        golden["pcm"][b].tofile(str(tmp_path / "cap.bin"))
+        out = subprocess.run([exe, str(tmp_path / "store.bin"), str(tmp_path / "cap.bin")], capture_output=True, text=True,
+                             timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert f"slot={golden['recg_best'][b]} dis={golden['recg_dis'][b]} " in out.stdout, out.stdout
+    np.full(16000, 2048, np.uint16).tofile(str(tmp_path / "cap.bin"))  # silence: NULL + dis_err everywhere
+    out = subprocess.run([exe, str(tmp_path / "store.bin"), str(tmp_path / "cap.bin")], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0 and "slot=-1 dis=4294967295" in out.stdout and "(null)" in out.stdout, out.stdout
