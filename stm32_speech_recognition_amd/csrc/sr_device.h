@@ -71,6 +71,8 @@ struct DtwArgs {
     const void *tplR;             // [tpl_rows][K] 32-byte rows: 12 x s16 | u32 squared norm | pad
     const uint32_t *tpl_frames_s; // [K]
     const uint32_t *tpl_orig;     // [K]
+    uint32_t lds_u;               // utterances per k_dtw_lds workgroup (0 -> generic kernel), see dtw_lds_pick_u
+    uint32_t lds_bytes;           // dynamic LDS of k_dtw_lds for that choice
 };
 
 void launch_vad(const VadArgs &a, hipStream_t s);
@@ -80,6 +82,9 @@ void launch_mfcc(const MfccArgs &a, hipStream_t s);
 uint32_t mfcc_frames_per_tile(uint32_t frame_len);      // frames one work item of the frame kernel covers
 uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on the current device
 void launch_dtw(const DtwArgs &a, hipStream_t s);
+// utterances per k_dtw_lds workgroup for K templates / max_frames rows (0 = use the generic kernel); tuning
+// override: environment variable SR_DTW_U, read when the template store is set
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer
 // generic complex 1024-point Q15 FFT, n arrays (cr4_fft_1024_stm32 semantics)

@@ -70,6 +70,7 @@ struct sr_engine {
     DevBuf<uint32_t> tplR;         // [rows][K] 32-byte rows (12 x s16 | norm | pad), templates ordered by length
     DevBuf<uint32_t> tpl_frames_s, tpl_orig;
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
+    uint32_t dtw_u = 0, dtw_lds = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
     DevBuf<sr_vad_rec> s_vad;
@@ -263,6 +264,11 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
         HIP_TRY(hipMemcpy(h->tpl_frames_s.p, fs.data(), K * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->tpl_orig.p, order.data(), K * 4, hipMemcpyHostToDevice));
     }
+    {
+        size_t lds = 0;
+        h->dtw_u = dtw_lds_pick_u(K, h->cfg.max_frames, &lds);
+        h->dtw_lds = (uint32_t)lds;
+    }
     h->K = K;
     h->tpl_rows = rows;
     h->tpl_stride = rows * kCoef;
@@ -429,6 +435,8 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.tplR = h->tplR.p;
     a.tpl_frames_s = h->tpl_frames_s.p;
     a.tpl_orig = h->tpl_orig.p;
+    a.lds_u = h->dtw_u;
+    a.lds_bytes = h->dtw_lds;
     return a;
 }
 

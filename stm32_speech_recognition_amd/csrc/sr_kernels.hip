@@ -1457,8 +1457,9 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
 {
     const uint64_t n = (uint64_t)a.B * a.K;
     if (!n) return;
-    size_t lds = 0;
-    const uint32_t U = a.tplR ? dtw_lds_pick_u(a.K, a.max_frames, &lds) : 0;
+    // U (utterances per workgroup) and the LDS size were chosen once, when the template store was set
+    const uint32_t U = a.tplR ? a.lds_u : 0;
+    const size_t lds = a.lds_bytes;
     if (U) {
         DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U};
         const uint32_t threads = (uint32_t)(((uint64_t)U * a.K + 63) / 64 * 64);
