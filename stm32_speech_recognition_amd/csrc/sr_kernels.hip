@@ -1265,6 +1265,35 @@ __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
     return (uint32_t)sqrt_rn_int((float)d);
 }
 
+// floor(sqrtf(f)) by bracketing: v_sqrt_f32 is within 1 ulp, so the correctly rounded root is s0 or one of its two
+// neighbours; when floor() of both neighbours agree the answer is known without the correction step.  `unsafe`
+// collects the (rare: ~1e-4 per value) cases that need sqrt_rn_int.  Validated for all 2^32 inputs by
+// tests/exhaustive_math_sweep.py through sr_math_diag.
+__device__ __forceinline__ uint32_t sqrt_floor_bracket(uint32_t d, bool &unsafe)
+{
+    const float s0 = __builtin_amdgcn_sqrtf((float)d);
+    const int si = __float_as_int(s0);
+    const uint32_t lo = (uint32_t)__int_as_float(si - 1), hi = (uint32_t)__int_as_float(si + 1);
+    unsafe |= (lo != hi);
+    return hi;
+}
+// three squared distances -> three (u32)sqrtf values (DTW.C:59)
+__device__ __forceinline__ void sqrt3(uint32_t &a, uint32_t &b, uint32_t &c)
+{
+    bool unsafe = false;
+    const uint32_t ra = sqrt_floor_bracket(a, unsafe), rb = sqrt_floor_bracket(b, unsafe), rc = sqrt_floor_bracket(c, unsafe);
+    if (__any(unsafe)) {  // wave-uniform: a few percent of the steps
+        a = (uint32_t)sqrt_rn_int((float)a);
+        b = (uint32_t)sqrt_rn_int((float)b);
+        c = (uint32_t)sqrt_rn_int((float)c);
+    } else {
+        a = ra;
+        b = rb;
+        c = rc;
+    }
+}
+__device__ __forceinline__ uint32_t dis2_from(uint32_t na, uint32_t nb, int dot) { return na + nb - 2u * (uint32_t)dot; }
+
 
 struct DtwLdsArgs {
     DtwArgs d;
@@ -1384,9 +1413,10 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]),
                         ni = row_from2(in_p[3], in_p[4], in_p[5], nrm_p[1]);
             // all three candidate distances, unconditionally (branch-free; masked to dis_err below)
-            const uint32_t d_up = dis_from(nm.w[6], ci.w[6], dot_rows(nm, ci));  // (x, y+1):   get_dis(mdl+12, in)
-            const uint32_t d_rt = dis_from(cm.w[6], ni.w[6], dot_rows(cm, ni));  // (x+1, y):   get_dis(mdl, in+12)
-            const uint32_t d_dg = dis_from(nm.w[6], ni.w[6], dot_rows(nm, ni));  // (x+1, y+1)
+            uint32_t d_up = dis2_from(nm.w[6], ci.w[6], dot_rows(nm, ci));  // (x, y+1):   get_dis(mdl+12, in)
+            uint32_t d_rt = dis2_from(cm.w[6], ni.w[6], dot_rows(cm, ni));  // (x+1, y):   get_dis(mdl, in+12)
+            uint32_t d_dg = dis2_from(nm.w[6], ni.w[6], dot_rows(nm, ni));  // (x+1, y+1)
+            sqrt3(d_up, d_rt, d_dg);
             // dtw_limit (DTW.C:76-109) as an interval test per column: (x', y') is inside  <=>  lb(x') <= y' <= ub(x')
             //   ub(x') = x' < X1 ? 2x'+1 : (x'+3-c1) >> 1      (negation of DTW.C:78-91; >> floors)
             //   lb(x') = x' < X2 ? x' >> 1 : 2x'+c2-3           (negation of DTW.C:93-106)
@@ -1624,7 +1654,11 @@ __global__ void k_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const
     if (i >= n) return;
     const uint32_t x = in[i];
     out[3 * i + 0] = log100_u32(x, log_thr);
-    out[3 * i + 1] = (uint32_t)sqrt_rn_int((float)x);
+    {
+        bool unsafe = false;
+        const uint32_t q = sqrt_floor_bracket(x, unsafe);
+        out[3 * i + 1] = unsafe ? (uint32_t)sqrt_rn_int((float)x) : q;  // exactly what sqrt3() returns per lane
+    }
     out[3 * i + 2] = (uint32_t)(sqrt_rn_int((float)(int)(x & 0x7FFFFFFFu)) * 10.0f);
 }
 void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s)
