@@ -67,6 +67,7 @@ struct sr_engine {
     DevBuf<int16_t> tpl;
     DevBuf<uint32_t> tpl_frames;
     DevBuf<uint8_t> tpl_valid;
+    bool tpl_staged_ok = true;     // every coefficient of the store fits the -2*coef rows of tplR
     DevBuf<uint32_t> tplR;         // [rows][K] 32-byte rows (12 x s16 | norm | pad), templates ordered by length
     DevBuf<uint32_t> tpl_frames_s, tpl_orig;
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
@@ -244,6 +245,11 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
             const uint32_t fx = v[x] ? f[x] : 0xFFFFFFFFu, fy = v[y] ? f[y] : 0xFFFFFFFFu;
             return fx < fy;
         });
+        // Rows hold -2*coef so that get_dis's sum of squares (DTW.C:51-57) becomes |m|^2 + |in|^2 + (-2m).in with the
+        // norm sum seeding the v_dot2 accumulator.  -2*coef must fit s16: coefficients outside [-16383, 16384]
+        // (unreachable for log-Mel cepstra, reachable for arbitrary s16 records) disable the staged kernel for
+        // this store and the generic k_dtw, which makes no such assumption, scores it.
+        bool fits = true;
         std::vector<uint32_t> rt((size_t)rows * K * 8, 0u), fs(K);
         for (uint32_t ks = 0; ks < K; ks++) {
             const uint32_t k = order[ks];
@@ -251,12 +257,18 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
             for (uint32_t r = 0; r < rows; r++) {
                 const int16_t *src = &m[((size_t)k * rows + r) * kCoef];
                 uint32_t *dst = &rt[((size_t)r * K + ks) * 8];
-                std::memcpy(dst, src, kCoef * 2);
+                int16_t neg2[kCoef];
                 uint32_t nrm = 0;
-                for (int c = 0; c < kCoef; c++) nrm += (uint32_t)((int32_t)src[c] * (int32_t)src[c]);
+                for (int c = 0; c < kCoef; c++) {
+                    nrm += (uint32_t)((int32_t)src[c] * (int32_t)src[c]);
+                    if (src[c] < -16383 || src[c] > 16384) fits = false;
+                    neg2[c] = (int16_t)(-2 * (int32_t)src[c]);
+                }
+                std::memcpy(dst, neg2, kCoef * 2);
                 dst[6] = nrm;
             }
         }
+        h->tpl_staged_ok = fits;
         if ((rc = h->tplR.reserve(rt.size()))) return rc;
         if ((rc = h->tpl_frames_s.reserve(K))) return rc;
         if ((rc = h->tpl_orig.reserve(K))) return rc;
@@ -266,7 +278,7 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     }
     {
         size_t lds = 0;
-        h->dtw_u = dtw_lds_pick_u(K, h->cfg.max_frames, &lds);
+        h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds) : 0;
         h->dtw_lds = (uint32_t)lds;
     }
     h->K = K;

@@ -539,8 +539,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
-                    const int re = sext_lo(u[e3][o]), im = sext_hi(u[e3][o]);
-                    const int r = mul24(re, re) + mul24(im, im);
+                    const int r = sdot2z(u[e3][o], u[e3][o]);  // re*re + im*im straight from the packed word
                     const uint32_t mag = (uint32_t)(sqrt_rn_int((float)r) * 10.0f);  // < 2^19
                     buf[lane + 64 * e3 + 256 * o] = umul24(mag, mag);
                 }
@@ -1297,7 +1296,7 @@ __device__ __forceinline__ uint32_t dis2_from(uint32_t na, uint32_t nb, int dot)
 
 struct DtwLdsArgs {
     DtwArgs d;
-    const u32x4 *tplR;          // [tpl_rows][K] 32-byte rows: 12 x s16 | u32 squared norm | pad ; length order
+    const u32x4 *tplR;          // [tpl_rows][K] 32-byte rows: 12 x s16 holding -2*coef | u32 squared norm | pad ; length order
     const uint32_t *tpl_frames_s;  // [K] frames, sorted order; 0 for invalid slots
     const uint32_t *tpl_orig;   // [K] original slot of sorted position
     uint32_t U;                 // utterances per workgroup
@@ -1334,6 +1333,15 @@ __device__ __forceinline__ Row32 row_from2(const u32x2 a, const u32x2 b, const u
 __device__ __forceinline__ int dot_rows(const Row32 &a, const Row32 &b)
 {
     int acc = sdot2z(a.w[0], b.w[0]);
+#pragma unroll
+    for (int i = 1; i < 6; i++) acc = sdot2(a.w[i], b.w[i], acc);
+    return acc;
+}
+
+// c + a.b over the 12 coefficients: the accumulator input carries the norm sum
+__device__ __forceinline__ int dot_rows_acc(const Row32 &a, const Row32 &b, int c)
+{
+    int acc = sdot2a(a.w[0], b.w[0], c);
 #pragma unroll
     for (int i = 1; i < 6; i++) acc = sdot2(a.w[i], b.w[i], acc);
     return acc;
@@ -1405,28 +1413,35 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         uint32_t dis;
         {
             const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]);
-            dis = dis_from(ci.w[6], cm.w[6], dot_rows(ci, cm));  // DTW.C:146
+            dis = (uint32_t)sqrt_rn_int((float)(uint32_t)dot_rows_acc(cm, ci, (int)(cm.w[6] + ci.w[6])));  // DTW.C:146
         }
+        // dtw_limit (DTW.C:76-109) as an interval test per column: (x', y') is inside  <=>  lb(x') <= y' <= ub(x')
+        //   ub(x') = x' < X1 ? 2x'+1 : (x'+3-c1) >> 1      (negation of DTW.C:78-91; >> floors)
+        //   lb(x') = x' < X2 ? x' >> 1 : 2x'+c2-3           (negation of DTW.C:93-106)
+        // The bounds of columns x (A) and x+1 (B) are carried; one new column is evaluated per step.
+        auto column = [&](int xx, int &lb, int &ub) {
+            ub = (xx < X1) ? 2 * xx + 1 : ((xx + c1s) >> 1);
+            lb = (xx < X2) ? (xx >> 1) : 2 * xx + c2s;
+        };
         int x = 1, y = 1;  // DTW.C:147-148
-        uint32_t step = 1;
+        int lbA, ubA, lbB, ubB;
+        column(1, lbA, ubA);
+        column(2, lbB, ubB);
+        uint32_t step = 1;  // u16 in the reference; cannot wrap here (steps < in_n + mdl_n <= 2R, R bounded by LDS)
         do {
             const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]),
                         ni = row_from2(in_p[3], in_p[4], in_p[5], nrm_p[1]);
-            // all three candidate distances, unconditionally (branch-free; masked to dis_err below)
-            uint32_t d_up = dis2_from(nm.w[6], ci.w[6], dot_rows(nm, ci));  // (x, y+1):   get_dis(mdl+12, in)
-            uint32_t d_rt = dis2_from(cm.w[6], ni.w[6], dot_rows(cm, ni));  // (x+1, y):   get_dis(mdl, in+12)
-            uint32_t d_dg = dis2_from(nm.w[6], ni.w[6], dot_rows(nm, ni));  // (x+1, y+1)
+            // all three candidate squared distances, unconditionally: |m|^2 + |i|^2 + (-2m).i, the norm sum seeds
+            // the dot2 accumulator (template rows are stored as -2m, see upload_templates)
+            uint32_t d_up = (uint32_t)dot_rows_acc(nm, ci, (int)(nm.w[6] + ci.w[6]));  // (x, y+1):   get_dis(mdl+12, in)
+            uint32_t d_rt = (uint32_t)dot_rows_acc(cm, ni, (int)(cm.w[6] + ni.w[6]));  // (x+1, y):   get_dis(mdl, in+12)
+            uint32_t d_dg = (uint32_t)dot_rows_acc(nm, ni, (int)(nm.w[6] + ni.w[6]));  // (x+1, y+1)
             sqrt3(d_up, d_rt, d_dg);
-            // dtw_limit (DTW.C:76-109) as an interval test per column: (x', y') is inside  <=>  lb(x') <= y' <= ub(x')
-            //   ub(x') = x' < X1 ? 2x'+1 : (x'+3-c1) >> 1      (negation of DTW.C:78-91; >> floors)
-            //   lb(x') = x' < X2 ? x' >> 1 : 2x'+c2-3           (negation of DTW.C:93-106)
-            const int xb = x + 1, y1 = y + 1;
-            const int ubA = (x < X1) ? 2 * x + 1 : ((x + c1s) >> 1), lbA = (x < X2) ? (x >> 1) : 2 * x + c2s;
-            const int ubB = (xb < X1) ? 2 * xb + 1 : ((xb + c1s) >> 1), lbB = (xb < X2) ? (xb >> 1) : 2 * xb + c2s;
-            // sign bit of (y'-lb) | (ub-y') is set exactly when the point is outside
-            const uint32_t up = (((y1 - lbA) | (ubA - y1)) < 0) ? SR_DIS_ERR : d_up;
-            const uint32_t right = (((y - lbB) | (ubB - y)) < 0) ? SR_DIS_ERR : d_rt;
-            const uint32_t diag = (((y1 - lbB) | (ubB - y1)) < 0) ? SR_DIS_ERR : d_dg;
+            const int y1 = y + 1;
+            const bool in_up = (lbA <= y1) & (y1 <= ubA), in_rt = (lbB <= y) & (y <= ubB), in_dg = (lbB <= y1) & (y1 <= ubB);
+            const uint32_t up = in_up ? d_up : SR_DIS_ERR, right = in_rt ? d_rt : SR_DIS_ERR, diag = in_dg ? d_dg : SR_DIS_ERR;
+            int lbN, ubN;
+            column(x + 2, lbN, ubN);
             uint32_t mn = diag;  // DTW.C:156-164
             if (mn > right) mn = right;
             if (mn > up) mn = up;
@@ -1437,6 +1452,10 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 x++;
                 in_p += 3;
                 nrm_p++;
+                lbA = lbB;
+                ubA = ubB;
+                lbB = lbN;
+                ubB = ubN;
             }
             if (adv_y) {
                 y++;
@@ -1444,7 +1463,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 tp += t_stride;
                 nm = row_from(tp[0], tp[1]);
             }
-            step = (step + 1) & 0xFFFF;
+            step++;
         } while (x < (int)in_n && y < (int)mdl_n);  // DTW.C:188
         score = dis / step;
     }

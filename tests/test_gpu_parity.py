@@ -176,14 +176,19 @@ def test_vad_stress_matches_oracle(eng119, oracle):
     assert nseg > 40
 
 
-def test_dtw_stress_matches_oracle():
+@pytest.mark.parametrize("tpl_lo,tpl_hi", [(-32768, 32767), (-16383, 16384)])
+def test_dtw_stress_matches_oracle(tpl_lo, tpl_hi):
+    """random s16 records, including full-scale ones.  The LDS-staged kernel stores templates as -2*coef, which
+    needs coefficients in [-16383, 16384]: the second case stays inside that range (both ends present) and runs
+    staged against full-scale inputs; the first case has coefficients outside it and must fall to k_dtw."""
     from stm32_speech_recognition_amd import Engine
     rng = np.random.default_rng(31)
     maxf, K, B = 200, 37, 64
     orc = ol.Oracle(max_frames=maxf)
     tf = rng.integers(1, maxf, K).astype(np.uint32)
     tm = rng.integers(-3000, 3000, (K, maxf + 1, 12)).astype(np.int16)
-    tm[::5] = rng.integers(-32768, 32767, (len(tm[::5]), maxf + 1, 12))
+    tm[::5] = rng.integers(tpl_lo, tpl_hi + 1, (len(tm[::5]), maxf + 1, 12))
+    tm[1, :, 0], tm[1, :, 1] = tpl_lo, tpl_hi
     inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
     im = rng.integers(-3000, 3000, (B, maxf, 12)).astype(np.int16)
     im[::4] = rng.integers(-32768, 32767, (len(im[::4]), maxf, 12))
