@@ -1271,9 +1271,8 @@ __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
 __device__ __forceinline__ uint32_t sqrt_floor_bracket(uint32_t d, bool &unsafe)
 {
     const float s0 = __builtin_amdgcn_sqrtf((float)d);
-    const int si = __float_as_int(s0);
-    const uint32_t lo = (uint32_t)__int_as_float(si - 1), hi = (uint32_t)__int_as_float(si + 1);
-    unsafe |= (lo != hi);
+    const uint32_t hi = (uint32_t)__int_as_float(__float_as_int(s0) + 1);  // floor(succ(s0))
+    unsafe |= !(s0 > (float)hi);  // s0 > hi  <=>  pred(s0) >= hi  <=>  floor(pred(s0)) == hi as well
     return hi;
 }
 // three squared distances -> three (u32)sqrtf values (DTW.C:59)
