@@ -153,6 +153,18 @@ int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32
 /* all-pairs greedy DTW of B feature sequences (in_mfcc[b*max_frames*n_coef], in_frames[b]) against the store */
 int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores,
                  sr_result *results);
+/* get_mdl (DTW.C:217-296; present in the reference but not called by main.c): template averaging.  For each of
+ * the P pairs the greedy dtw() path of (in1 as input, in2 as model) is walked and the start point plus every point
+ * the walk moves to contributes one merged frame, the per-coefficient get_mean (DTW.C:195-205) (a + b) / 2 in int
+ * arithmetic.  in1 [P][rows1][12], in2 [P][rows2][12] (host); rows past n are read as by dtw() (one slack row).
+ * mdl [P][mdl_rows][12] receives the merged templates (rows past the merged length are zero);
+ * mdl_frames[p] = number of merged frames = step (DTW.C:293) -- when it exceeds mdl_rows only the first mdl_rows
+ * frames were stored (the reference would overrun its 119-frame record); dis[p] = dis/step.  Pairs whose length ratio
+ * is outside 1/2..2 give dis = 0xFFFFFFFF, mdl_frames = 0 and an all-zero mdl (DTW.C:236-239). */
+int sr_get_mdl_batch(sr_engine *h, const int16_t *in1, const uint32_t *n1, uint32_t rows1, const int16_t *in2,
+                     const uint32_t *n2, uint32_t rows2, uint32_t P, int16_t *mdl, uint32_t mdl_rows,
+                     uint32_t *mdl_frames, uint32_t *dis);
+
 /* OPT-IN, NON-REFERENCE scorer: full dynamic-programming DTW (anti-diagonal wavefront across the 64-lane wave,
  * template staged in LDS) with the reference's parallelogram (dtw_limit) and local distance (get_dis):
  *   D(1,1)=d(1,1); D(x,y)=d(x,y)+min(D(x-1,y-1),D(x-1,y),D(x,y-1)); score = D(in,mdl)/(in+mdl), dis_err if gated/unreachable.
@@ -212,6 +224,8 @@ uint32_t get_dis(int16_t *frm_ftr1, int16_t *frm_ftr2);                         
 uint8_t dtw_limit(uint16_t x, uint16_t y);                                                       /* DTW.C:76 */
 uint32_t dtw(v_ftr_tag *ftr_in, v_ftr_tag *frt_mdl);                                             /* DTW.H:7, DTW.C:120 */
 uint8_t *spch_recg(uint16_t *v_dat, uint32_t *mtch_dis);                                         /* main.c:249 */
+void get_mean(int16_t *frm_ftr1, int16_t *frm_ftr2, int16_t *mean);                              /* DTW.C:195 */
+uint32_t get_mdl(v_ftr_tag *ftr_in1, v_ftr_tag *ftr_in2, v_ftr_tag *ftr_mdl);                    /* DTW.C:217 */
 /* BASELINE.json's north-star spellings; they do not exist in the reference -> aliases of get_mfcc */
 void GetMfcc(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg);
 void MFCC_Comp(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg);

@@ -419,6 +419,67 @@ uint32_t sr_oracle_dtw(const int16_t *in, uint32_t in_n, const int16_t *mdl, uin
     return dis / step;
 }
 
+/* ---- DTW.C:195-205 get_mean and DTW.C:217-296 get_mdl (not called by the reference's main.c) -------------
+ * get_mdl walks exactly the dtw() path of (in1 as "in", in2 as "mdl") and emits, for the start point and after
+ * every move, the per-coefficient mean (a+b)/2 (int arithmetic, truncation toward zero) of the two frames the
+ * cursors are on; the merged template has `step` frames (DTW.C:291).  Rows beyond out_rows are not written
+ * (the reference would run past its 119-frame record there).  Returns dis/step, or dis_err for length ratios
+ * outside 1/2..2 (then nothing is written and *out_frames = 0). */
+void sr_oracle_get_mean(const int16_t *a, const int16_t *b, int16_t *mean, uint32_t nc)
+{
+    for (uint32_t i = 0; i < nc; i++)
+        mean[i] = (int16_t)(((int)a[i] + (int)b[i]) / 2);
+}
+
+uint32_t sr_oracle_get_mdl(const int16_t *in, uint32_t in_n, const int16_t *mdl, uint32_t mdl_n, uint32_t nc,
+                           int16_t *out, uint32_t out_rows, uint32_t *out_frames)
+{
+    uint32_t dis, step, x, y;
+    int X1, X2;
+    *out_frames = 0;
+    if (in_n > mdl_n * 2 || 2 * in_n < mdl_n)
+        return SR_ORACLE_DIS_ERR;
+    X1 = (int)(uint16_t)((2 * (int)mdl_n - (int)in_n) / 3);
+    X2 = (int)(uint16_t)((4 * (int)in_n - 2 * (int)mdl_n) / 3);
+    dis = sr_oracle_get_dis(in, mdl, nc);
+    if (out_rows > 0)
+        sr_oracle_get_mean(in, mdl, out, nc);
+    x = y = step = 1;
+    do {
+        uint32_t up, right, diag, mn;
+        up = dtw_outside((int)x, (int)y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_ORACLE_DIS_ERR
+                                                                             : sr_oracle_get_dis(mdl + nc, in, nc);
+        right = dtw_outside((int)x + 1, (int)y, X1, X2, (int)in_n, (int)mdl_n) ? SR_ORACLE_DIS_ERR
+                                                                                : sr_oracle_get_dis(mdl, in + nc, nc);
+        diag = dtw_outside((int)x + 1, (int)y + 1, X1, X2, (int)in_n, (int)mdl_n)
+                   ? SR_ORACLE_DIS_ERR
+                   : sr_oracle_get_dis(mdl + nc, in + nc, nc);
+        mn = diag;
+        if (mn > right)
+            mn = right;
+        if (mn > up)
+            mn = up;
+        dis += mn;
+        if (mn == diag) {
+            in += nc;
+            x++;
+            mdl += nc;
+            y++;
+        } else if (mn == up) {
+            mdl += nc;
+            y++;
+        } else {
+            in += nc;
+            x++;
+        }
+        if (step < out_rows) /* row index = step before the increment (DTW.C:286-287) */
+            sr_oracle_get_mean(in, mdl, out + (size_t)step * nc, nc);
+        step = (uint16_t)(step + 1);
+    } while (x < in_n && y < mdl_n);
+    *out_frames = step;
+    return dis / step;
+}
+
 /* the three non-integer expressions of the path on their own (same C expressions as MFCC.C:168, DTW.C:59, MFCC.C:56-58) */
 void sr_oracle_math_diag(const uint32_t *in, uint32_t *out, uint32_t n)
 {

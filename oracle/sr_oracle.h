@@ -86,6 +86,9 @@ uint32_t sr_oracle_dtw(const int16_t *in, uint32_t in_frames, const int16_t *mdl
                        uint32_t n_coef);
 
 /* out[3i] = (u32)(log((double)x)*100), out[3i+1] = (u32)sqrtf((float)x), out[3i+2] = (u32)(sqrtf((float)(s32)(x&0x7fffffff))*10) */
+void sr_oracle_get_mean(const int16_t *a, const int16_t *b, int16_t *mean, uint32_t nc);           /* DTW.C:195-205 */
+uint32_t sr_oracle_get_mdl(const int16_t *in, uint32_t in_n, const int16_t *mdl, uint32_t mdl_n, uint32_t nc,
+                           int16_t *out, uint32_t out_rows, uint32_t *out_frames);                  /* DTW.C:217-296 */
 void sr_oracle_math_diag(const uint32_t *in, uint32_t *out, uint32_t n);
 
 /* NON-REFERENCE extension (own definition, see sr_oracle.c): full-DP DTW with the same parallelogram and distance. */

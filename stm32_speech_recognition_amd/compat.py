@@ -36,6 +36,7 @@ def _lib():
     L.fft.restype = C.POINTER(C.c_uint32)
     L.get_dis.restype = C.c_uint32
     L.dtw.restype = C.c_uint32
+    L.get_mdl.restype = C.c_uint32
     L.dtw_limit.restype = C.c_uint8
     L.spch_recg.restype = C.c_void_p
     return L
@@ -105,6 +106,22 @@ def make_ftr(mfcc, n, save_sign=12345):
 
 def dtw(ftr_in, ftr_mdl):
     return _lib().dtw(C.byref(ftr_in), C.byref(ftr_mdl))
+
+
+def get_mdl(ftr_in1, ftr_in2):
+    """DTW.C:217-296.  Returns (dis, merged v_ftr_tag)."""
+    out = v_ftr_tag()
+    dis = _lib().get_mdl(C.byref(ftr_in1), C.byref(ftr_in2), C.byref(out))
+    return dis, out
+
+
+def get_mean(a, b):
+    """DTW.C:195-205 on two 12-coefficient frames."""
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    b = np.ascontiguousarray(b, dtype=np.int16)
+    m = np.zeros(MFCC_NUM, dtype=np.int16)
+    _lib().get_mean(_addr(a), _addr(b), _addr(m))
+    return m
 
 
 def set_templates(store, stride=4096):

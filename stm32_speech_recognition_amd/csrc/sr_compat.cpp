@@ -191,6 +191,50 @@ uint32_t dtw(v_ftr_tag *ftr_in, v_ftr_tag *frt_mdl)
     return score;
 }
 
+// DTW.C:217-296.  ftr_mdl->save_sign is left alone, frm_num = step (DTW.C:293).  A merged template longer than
+// the 119-frame record (the reference would write past it) is a fatal error here.
+uint32_t get_mdl(v_ftr_tag *ftr_in1, v_ftr_tag *ftr_in2, v_ftr_tag *ftr_mdl)
+{
+    sr_engine *h = pair_engine("get_mdl");
+    const uint32_t n1 = ftr_in1->frm_num, n2 = ftr_in2->frm_num;
+    if (n1 > SR_VV_FRM_MAX || n2 > SR_VV_FRM_MAX) {
+        std::fprintf(stderr, "get_mdl: frm_num outside the v_ftr_tag capacity\n");
+        std::abort();
+    }
+    g_in_frm = (uint16_t)n1;  // DTW.C:229-230: the file statics dtw_limit() reads
+    g_mdl_frm = (uint16_t)n2;
+    if (n1 > n2 * 2 || 2 * n1 < n2) return SR_DIS_ERR;  // DTW.C:232-235, ftr_mdl untouched
+    g_X1 = (uint16_t)((2 * g_mdl_frm - g_in_frm) / 3);
+    g_X2 = (uint16_t)((4 * g_in_frm - 2 * g_mdl_frm) / 3);
+    if (n1 == 0 || n2 == 0) {
+        std::fprintf(stderr, "get_mdl: empty record\n");
+        std::abort();
+    }
+    std::vector<int16_t> out((size_t)SR_VV_FRM_MAX * 12);
+    uint32_t frames = 0, dis = 0;
+    if (sr_get_mdl_batch(h, ftr_in1->mfcc_dat, &n1, SR_VV_FRM_MAX, ftr_in2->mfcc_dat, &n2, SR_VV_FRM_MAX, 1, out.data(),
+                         SR_VV_FRM_MAX, &frames, &dis) != SR_OK)
+        die("get_mdl");
+    if (frames > SR_VV_FRM_MAX) {
+        std::fprintf(stderr, "get_mdl: merged template has %u frames, the v_ftr_tag record holds %d\n", frames, SR_VV_FRM_MAX);
+        std::abort();
+    }
+    std::memcpy(ftr_mdl->mfcc_dat, out.data(), (size_t)frames * 12 * sizeof(int16_t));
+    ftr_mdl->frm_num = (uint16_t)frames;
+    return dis;
+}
+
+// DTW.C:195-205: one frame pair = get_mdl of two 1-frame records, first merged frame
+void get_mean(int16_t *frm_ftr1, int16_t *frm_ftr2, int16_t *mean)
+{
+    sr_engine *h = pair_engine("get_mean");
+    const uint32_t one = 1;
+    uint32_t frames = 0, dis = 0;
+    int16_t out[12];
+    if (sr_get_mdl_batch(h, frm_ftr1, &one, 1, frm_ftr2, &one, 1, 1, out, 1, &frames, &dis) != SR_OK) die("get_mean");
+    std::memcpy(mean, out, sizeof(out));
+}
+
 // main.c:249-296
 uint8_t *spch_recg(uint16_t *v_dat, uint32_t *mtch_dis)
 {

@@ -75,6 +75,22 @@ struct DtwArgs {
     uint32_t lds_bytes;           // dynamic LDS of k_dtw_lds for that choice
 };
 
+// get_mdl (DTW.C:217-296): P independent pairs
+struct GetMdlArgs {
+    const int16_t *in1;     // [P][rows1][12]
+    const uint32_t *n1;     // [P] frames of in1 ("in" role)
+    uint32_t rows1;
+    const int16_t *in2;     // [P][rows2][12]
+    const uint32_t *n2;     // [P] frames of in2 ("mdl" role)
+    uint32_t rows2;
+    uint32_t P;
+    int16_t *mdl;           // [P][mdl_rows][12] merged templates
+    uint32_t mdl_rows;
+    uint32_t *mdl_frames;   // [P] step count = frames of the merged template (may exceed mdl_rows), 0 on dis_err
+    uint32_t *dis;          // [P] dis/step or dis_err
+};
+void launch_get_mdl(const GetMdlArgs &a, hipStream_t s);
+
 void launch_vad(const VadArgs &a, hipStream_t s);
 void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
                            uint32_t frame_len, uint32_t hop, hipStream_t s);

@@ -756,6 +756,39 @@ int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames
     return SR_OK;
 }
 
+// get_mdl (DTW.C:217-296): merge pairs of feature records along their greedy DTW path
+int sr_get_mdl_batch(sr_engine *h, const int16_t *in1, const uint32_t *n1, uint32_t rows1, const int16_t *in2,
+                     const uint32_t *n2, uint32_t rows2, uint32_t P, int16_t *mdl, uint32_t mdl_rows,
+                     uint32_t *mdl_frames, uint32_t *dis)
+{
+    if (!h || !in1 || !n1 || !in2 || !n2 || !mdl_frames || !dis || (mdl_rows && !mdl))
+        return fail(SR_ERR_BAD_ARG, "null argument");
+    if (P == 0) return SR_OK;
+    if (rows1 == 0 || rows2 == 0) return fail(SR_ERR_BAD_ARG, "rows1 / rows2 must be at least 1");
+    for (uint32_t p = 0; p < P; p++)
+        if (n1[p] > rows1 || n2[p] > rows2 || n1[p] > 0xFFFF || n2[p] > 0xFFFF)
+            return fail(SR_ERR_BAD_ARG, "frame count exceeds the rows of its record (or the u16 range)");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    const size_t e1 = (size_t)P * rows1 * kCoef, e2 = (size_t)P * rows2 * kCoef, eo = (size_t)P * mdl_rows * kCoef;
+    if ((rc = h->s_mfcc.reserve(e1 + e2 + eo + 16))) return rc;
+    if ((rc = h->s_u32a.reserve((size_t)2 * P))) return rc;
+    if ((rc = h->s_u32b.reserve((size_t)2 * P))) return rc;
+    int16_t *d1 = h->s_mfcc.p, *d2 = d1 + ((e1 + 3) & ~(size_t)3), *dm = d2 + ((e2 + 3) & ~(size_t)3);  // 8-byte aligned rows
+    HIP_TRY(hipMemcpy(d1, in1, e1 * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d2, in2, e2 * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->s_u32a.p, n1, (size_t)P * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->s_u32a.p + P, n2, (size_t)P * 4, hipMemcpyHostToDevice));
+    if (eo) HIP_TRY(hipMemset(dm, 0, eo * 2));
+    GetMdlArgs a{d1, h->s_u32a.p, rows1, d2, h->s_u32a.p + P, rows2, P, dm, mdl_rows, h->s_u32b.p, h->s_u32b.p + P};
+    launch_get_mdl(a, nullptr);
+    HIP_TRY(hipGetLastError());
+    if (eo) HIP_TRY(hipMemcpy(mdl, dm, eo * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mdl_frames, h->s_u32b.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dis, h->s_u32b.p + P, (size_t)P * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 // OPT-IN, NON-REFERENCE: full dynamic-programming DTW with the reference's parallelogram and local distance
 // (see k_dtw_dp).  Never used by sr_recognize_* or the dtw() symbol.
 int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_in_frames, const sr_vad_rec *d_vad,

@@ -1229,6 +1229,80 @@ __device__ uint32_t dtw_pair(const int16_t *in, uint32_t in_n, uint32_t in_rows,
     return dis / step;
 }
 
+// ---- get_mdl (DTW.C:217-296) + get_mean (DTW.C:195-205): template averaging, one lane per pair --------------
+// The same greedy walk as dtw_pair with in1 in the "in" role and in2 in the "mdl" role; the start point and every
+// point the walk moves to contribute one merged frame = per-coefficient (a + b) / 2 in int arithmetic (truncation
+// toward zero).  The merged template has `step` frames; frames >= out_rows are dropped (the reference would write
+// past its 119-frame record there).
+__device__ __forceinline__ uint32_t mean_word(uint32_t a, uint32_t b)
+{
+    const int lo = (sext_lo(a) + sext_lo(b)) / 2, hi = (sext_hi(a) + sext_hi(b)) / 2;
+    return pack16(lo, hi);
+}
+__device__ __forceinline__ void store_mean(int16_t *row, const Frame12 &a, const Frame12 &b)
+{
+    uint2 *q = (uint2 *)row;
+    q[0] = make_uint2(mean_word(a.w[0], b.w[0]), mean_word(a.w[1], b.w[1]));
+    q[1] = make_uint2(mean_word(a.w[2], b.w[2]), mean_word(a.w[3], b.w[3]));
+    q[2] = make_uint2(mean_word(a.w[4], b.w[4]), mean_word(a.w[5], b.w[5]));
+}
+
+__global__ void __launch_bounds__(64) k_get_mdl(const GetMdlArgs a)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.P) return;
+    const uint32_t in_n = a.n1[p], mdl_n = a.n2[p];
+    const int16_t *in = a.in1 + (size_t)p * a.rows1 * kCoef, *mdl = a.in2 + (size_t)p * a.rows2 * kCoef;
+    int16_t *out = a.mdl + (size_t)p * a.mdl_rows * kCoef;
+    if (in_n == 0 || mdl_n == 0 || in_n > mdl_n * 2 || 2 * in_n < mdl_n) {  // DTW.C:236-239
+        a.dis[p] = SR_DIS_ERR;
+        a.mdl_frames[p] = 0;
+        return;
+    }
+    const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);
+    const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
+    uint32_t px = 0, py = 0;
+    Frame12 ci = load_frame(in), cm = load_frame(mdl);
+    uint32_t nci = norm2(ci), ncm = norm2(cm);
+    uint32_t dis = get_dis_dev(ci, nci, cm, ncm);
+    if (a.mdl_rows) store_mean(out, ci, cm);  // DTW.C:250-251
+    uint32_t step = 1;
+    do {
+        const uint32_t rx = (px + 1 < a.rows1) ? px + 1 : a.rows1 - 1, ry = (py + 1 < a.rows2) ? py + 1 : a.rows2 - 1;
+        const Frame12 ni = load_frame(in + (size_t)rx * kCoef), nm = load_frame(mdl + (size_t)ry * kCoef);
+        const uint32_t nni = norm2(ni), nnm = norm2(nm);
+        const int x = (int)px + 1, y = (int)py + 1;
+        const uint32_t up = dtw_out(x, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_dev(nm, nnm, ci, nci);
+        const uint32_t right = dtw_out(x + 1, y, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_dev(cm, ncm, ni, nni);
+        const uint32_t diag =
+            dtw_out(x + 1, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_dev(nm, nnm, ni, nni);
+        uint32_t mn = diag;  // DTW.C:260-268
+        if (mn > right) mn = right;
+        if (mn > up) mn = up;
+        dis += mn;
+        const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:272-288
+        if (mv_diag || !mv_up) {
+            ci = ni;
+            nci = nni;
+            px++;
+        }
+        if (mv_diag || mv_up) {
+            cm = nm;
+            ncm = nnm;
+            py++;
+        }
+        if (step < a.mdl_rows) store_mean(out + (size_t)step * kCoef, ci, cm);  // DTW.C:286-287 (row = step before ++)
+        step = (step + 1) & 0xFFFF;
+    } while (px + 1 < in_n && py + 1 < mdl_n);  // DTW.C:291
+    a.mdl_frames[p] = step;  // DTW.C:293
+    a.dis[p] = dis / step;
+}
+void launch_get_mdl(const GetMdlArgs &a, hipStream_t s)
+{
+    if (!a.P) return;
+    hipLaunchKernelGGL(k_get_mdl, dim3((a.P + 63) / 64), dim3(64), 0, s, a);
+}
+
 __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
 {
     const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1672,10 +1746,12 @@ __global__ void k_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const
     if (i >= n) return;
     const uint32_t x = in[i];
     out[3 * i + 0] = log100_u32(x, log_thr);
+    // the exact routine and the bracketed fast path of the DTW kernel are reported through one word: the exact value,
+    // or a poison value if the fast path claims "safe" and disagrees (tests/exhaustive_math_sweep.py: all 2^32 inputs)
     {
         bool unsafe = false;
-        const uint32_t q = sqrt_floor_bracket(x, unsafe);
-        out[3 * i + 1] = unsafe ? (uint32_t)sqrt_rn_int((float)x) : q;  // exactly what sqrt3() returns per lane
+        const uint32_t q = sqrt_floor_bracket(x, unsafe), e = (uint32_t)sqrt_rn_int((float)x);
+        out[3 * i + 1] = (unsafe || q == e) ? e : 0xDEAD0001u;
     }
     out[3 * i + 2] = (uint32_t)(sqrt_rn_int((float)(int)(x & 0x7FFFFFFFu)) * 10.0f);
 }

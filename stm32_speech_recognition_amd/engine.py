@@ -197,6 +197,23 @@ class Engine:
         self._check(self.L.sr_dtw_dp_batch(self.h, _vp(in_mfcc), _vp(in_frames), C.c_uint32(B), _vp(sc)))
         return sc
 
+    def get_mdl(self, in1, n1, in2, n2, mdl_rows):
+        """get_mdl (DTW.C:217-296) on P pairs: in1 int16 [P, rows1, 12], in2 int16 [P, rows2, 12].
+        Returns (mdl int16 [P, mdl_rows, 12], mdl_frames uint32 [P], dis uint32 [P])."""
+        in1 = np.ascontiguousarray(in1, dtype=np.int16)
+        in2 = np.ascontiguousarray(in2, dtype=np.int16)
+        n1 = np.ascontiguousarray(n1, dtype=np.uint32)
+        n2 = np.ascontiguousarray(n2, dtype=np.uint32)
+        P = in1.shape[0]
+        assert in1.shape[2] == N_COEF and in2.shape[2] == N_COEF and in2.shape[0] == P
+        mdl = np.zeros((P, mdl_rows, N_COEF), dtype=np.int16)
+        frames = np.zeros(P, dtype=np.uint32)
+        dis = np.zeros(P, dtype=np.uint32)
+        self._check(self.L.sr_get_mdl_batch(self.h, _vp(in1), _vp(n1), C.c_uint32(in1.shape[1]), _vp(in2), _vp(n2),
+                                            C.c_uint32(in2.shape[1]), C.c_uint32(P), _vp(mdl), C.c_uint32(mdl_rows),
+                                            _vp(frames), _vp(dis)))
+        return mdl, frames, dis
+
     def fft_q15(self, words):
         """cr4_fft_1024_stm32 on uint32 [n, 1024] packed complex arrays."""
         words = np.ascontiguousarray(words, dtype=np.uint32)

@@ -124,6 +124,23 @@ def main():
         dd[p] = r.dtw(ol.RefLib.make_ftr(a, na), ol.RefLib.make_ftr(bb, nb))
     g["dtw_len"], g["dtw_a"], g["dtw_b"], g["dtw_dis"] = dl, da, db, dd
 
+    # --- get_mdl (DTW.C:217-296, template averaging) by the reference's own object on the first PM of those pairs.
+    # Records are followed by one zero frame so the reference's read of the frame after the last one is defined;
+    # merged templates longer than 119 frames are kept in full (the wrapper over-allocates the output record).
+    PM = 150
+    md = np.zeros(PM, dtype=np.uint32)
+    mn = np.zeros(PM, dtype=np.uint32)
+    mm = np.zeros((PM, 238, 12), dtype=np.int16)
+    zrow = np.zeros(24, dtype=np.uint8)
+    for p in range(PM):
+        f1 = np.concatenate([ol.RefLib.make_ftr(da[p], dl[p, 0]), zrow])
+        f2 = np.concatenate([ol.RefLib.make_ftr(db[p], dl[p, 1]), zrow])
+        md[p], n, rows = r.get_mdl(f1, f2)
+        if md[p] != 0xFFFFFFFF:
+            mn[p] = n
+            mm[p, :n] = rows
+    g["mdl_dis"], g["mdl_frames"], g["mdl_rows"] = md, mn, mm
+
     # --- multi-word captures: every VAD segment through the reference objects (get_mfcc + dtw per segment).
     #     Appended last so the random stream of the sections above stays as it was.
     M = 6

@@ -142,6 +142,17 @@ class Oracle:
         b = np.ascontiguousarray(b, dtype=np.int16)
         return self.L.sr_oracle_dtw(_p(a), C.c_uint32(na), _p(b), C.c_uint32(nb), C.c_uint32(self.n_coef))
 
+    def get_mdl(self, a, na, b, nb, out_rows):
+        """DTW.C:217-296.  a, b as for dtw().  Returns (dis, merged frame count, int16 [min(count, out_rows), n_coef])."""
+        a = np.ascontiguousarray(a, dtype=np.int16)
+        b = np.ascontiguousarray(b, dtype=np.int16)
+        out = np.zeros((max(out_rows, 1), self.n_coef), dtype=np.int16)
+        nf = C.c_uint32(0)
+        self.L.sr_oracle_get_mdl.restype = C.c_uint32
+        dis = self.L.sr_oracle_get_mdl(_p(a), C.c_uint32(na), _p(b), C.c_uint32(nb), C.c_uint32(self.n_coef), _p(out),
+                                       C.c_uint32(out_rows), C.byref(nf))
+        return dis, nf.value, out[:min(nf.value, out_rows)].copy()
+
     def make_templates(self, tpl_mfcc, tpl_frames, tpl_valid=None):
         """tpl_mfcc: int16 [K, Tt, n_coef] (Tt >= max frames + 1)."""
         tpl_mfcc = np.ascontiguousarray(tpl_mfcc, dtype=np.int16)
@@ -243,6 +254,15 @@ class RefLib:
 
     def dtw(self, ftr_in, ftr_mdl):
         return self.L.dtw(_p(ftr_in), _p(ftr_mdl))
+
+    def get_mdl(self, ftr_in1, ftr_in2):
+        """the reference's own get_mdl (DTW.C:217-296).  The output record is over-allocated to 2*119 frames because
+        the reference writes `step` frames, which can exceed the 119-frame v_ftr_tag.  Returns (dis, step, rows)."""
+        self.L.get_mdl.restype = C.c_uint32
+        out = np.zeros(4 + 24 * 240, dtype=np.uint8)
+        dis = self.L.get_mdl(_p(ftr_in1), _p(ftr_in2), _p(out))
+        n = int(out.view(np.uint16)[1])
+        return dis, n, out[4:].view(np.int16)[:n * 12].reshape(n, 12).copy()
 
     def spch_recg(self, pcm, store, stride=4096, noise_len=2400, seg_idx=0):
         """store: uint8 [n_slots*stride] flash-style image.  Returns (status, best_slot, dis, scores, mfcc, n)."""

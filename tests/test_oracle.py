@@ -114,6 +114,24 @@ def test_dtw_matches_golden(oracle, golden):
     assert (dd == ol.DIS_ERR).sum() > 20 and (dd != ol.DIS_ERR).sum() > 100
 
 
+def test_get_mdl_matches_golden(oracle, golden):
+    """template averaging (DTW.C:217-296): merged frames, frame count and distance from the reference's own get_mdl"""
+    ln, da, db = golden["dtw_len"], golden["dtw_a"], golden["dtw_b"]
+    md, mn, mm = golden["mdl_dis"], golden["mdl_frames"], golden["mdl_rows"]
+    pad = np.zeros((1, 12), dtype=np.int16)
+    for p in range(len(md)):
+        dis, n, rows = oracle.get_mdl(np.concatenate([da[p], pad]), ln[p, 0], np.concatenate([db[p], pad]), ln[p, 1], 238)
+        assert dis == md[p] and n == mn[p] and np.array_equal(rows, mm[p, :n]), p
+        if dis != ol.DIS_ERR:
+            assert dis == golden["dtw_dis"][p]            # same walk as dtw()
+            assert min(ln[p]) <= n <= max(ln[p].sum() - 1, 2)   # the walk stops when either sequence ends
+    assert (md != ol.DIS_ERR).sum() > 60 and (mn > 119).sum() > 10  # includes merged templates the 119-frame record cannot hold
+    # clipping: only out_rows frames are stored, the count still reports the full length
+    p = int(np.argmax(mn))
+    dis, n, rows = oracle.get_mdl(np.concatenate([da[p], pad]), ln[p, 0], np.concatenate([db[p], pad]), ln[p, 1], 50)
+    assert n == mn[p] and rows.shape[0] == 50 and np.array_equal(rows, mm[p, :50])
+
+
 def store_to_templates(store, stride=4096, tmax=120, nc=12):
     """Firmware flash image (Flash.H:11-20, MFCC.H:18-25) -> dense batched layout."""
     K = len(store) // stride
