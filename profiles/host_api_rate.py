@@ -1,0 +1,60 @@
+"""PCIe-inclusive rate of the host-buffer boundary (sr_recognize_batch): capture buffers in host memory ->
+results in host memory.  Never the bench `value` (that one starts with inputs resident in HBM); DESIGN.md 6 quotes it.
+    python profiles/host_api_rate.py [B]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stm32_speech_recognition_amd import Engine, synth  # noqa: E402
+from stm32_speech_recognition_amd.engine import vad_from_torch  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+    T, K, NW = 256, 100, 25
+    dev = torch.device("cuda", 0)
+    eng = Engine(max_frames=320, device=0)
+    bank = synth.word_bank(NW)
+    rng = np.random.default_rng(2026)
+    tfr = rng.integers(192, 321, K)
+    tp = synth.make_utterances(np.arange(K) % NW, tfr, seed=77, bank=bank, S=synth.buf_len_for(320), device=dev)
+    tvad, tmf = eng.features_dev(tp)
+    torch.cuda.synchronize()
+    tm = np.concatenate([tmf.cpu().numpy(), np.zeros((K, 1, 12), np.int16)], 1)
+    eng.set_templates_dense(tm, vad_from_torch(tvad)["frm_num"].astype(np.uint32))
+    S = synth.buf_len_for(T)
+    words = rng.integers(0, NW, B)
+    d_pcm = synth.make_utterances(words, [T] * B, seed=1000, bank=bank, S=S, device=dev)
+    out = {}
+    for name, host in (("pageable", d_pcm.cpu().numpy().view(np.uint16)),
+                       ("pinned", d_pcm.cpu().pin_memory().numpy().view(np.uint16))):
+        res0 = eng.recognize(host, want_scores=False, want_mfcc=False, want_vad=False)["results"]  # warm-up (allocations)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = eng.recognize(host, want_scores=False, want_mfcc=False, want_vad=False)["results"]
+            ts.append(time.perf_counter() - t0)
+        assert np.array_equal(res, res0)
+        t = min(ts)
+        out[name] = {"ms": round(t * 1e3, 2), "utt_per_s": round(B / t), "upload_GBps": round(B * S * 2 / t / 1e9, 1)}
+    o = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
+    eng.recognize_dev(d_pcm, o)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.recognize_dev(d_pcm, o)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    out["device_resident"] = {"ms": round(t * 1e3, 2), "utt_per_s": round(B / t)}
+    assert np.array_equal(o["results"].cpu().numpy().view(np.uint32).reshape(B, 4)[:, 0], res["best_tpl"])
+    out["B"], out["buf_len"] = B, S
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

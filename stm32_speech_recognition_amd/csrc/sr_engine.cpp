@@ -82,6 +82,9 @@ struct sr_engine {
     DevBuf<sr_atap> s_atap;
     DevBuf<sr_vad_rec> s_vad2;
     // profiling: one set of 5 events per profiled call since the last sr_set_profiling(h, 1)
+    // host-buffer pipeline (sr_recognize_batch): upload of chunk c+1 overlaps the kernels of chunk c
+    hipStream_t st_copy = nullptr, st_comp = nullptr;
+    std::vector<hipEvent_t> ev_chunk;
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // 5 per call
     size_t ev_used = 0;          // calls recorded
@@ -220,6 +223,9 @@ void sr_destroy(sr_engine *h)
     h->s_atap.release();
     h->s_vad2.release();
     for (auto &e : h->ev) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_chunk) (void)hipEventDestroy(e);
+    if (h->st_copy) (void)hipStreamDestroy(h->st_copy);
+    if (h->st_comp) (void)hipStreamDestroy(h->st_comp);
     delete h;
 }
 
@@ -576,16 +582,49 @@ int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
     if (B == 0) return SR_OK;
     if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
     HIP_TRY(hipSetDevice(h->device));
-    uint64_t ds = 0;
-    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
-    if (rc) return rc;
+    const uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
+    int rc;
+    if ((rc = h->s_pcm.reserve((size_t)B * ds))) return rc;
     if ((rc = h->s_results.reserve(B))) return rc;
     if ((rc = h->s_vad.reserve(B))) return rc;
     if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
     if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
-    rc = sr_recognize_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_results.p, h->s_scores.p, h->s_mfcc.p, h->s_vad.p,
-                                nullptr);
-    if (rc) return rc;
+    // The upload dominates (2*buf_len bytes per utterance over PCIe vs ~0.5 us of kernels): split the batch into
+    // chunks and let the upload of chunk c+1 run on the copy stream while chunk c is processed on the compute
+    // stream.  hipMemcpy2DAsync from pageable memory returns when the host buffer has been consumed, so the host
+    // thread paces the copies; kernels are only enqueued.  Results come back once, after the last chunk.
+    const uint32_t n_chunks = (B >= 2048) ? std::min<uint32_t>(16, B / 1024) : 1;
+    if (n_chunks <= 1 || h->profiling) {
+        HIP_TRY(hipMemcpy2D(h->s_pcm.p, ds * 2, pcm, pcm_stride * 2, (size_t)buf_len * 2, B, hipMemcpyHostToDevice));
+        rc = sr_recognize_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_results.p, h->s_scores.p, h->s_mfcc.p, h->s_vad.p,
+                                    nullptr);
+        if (rc) return rc;
+    } else {
+        if (!h->st_copy) HIP_TRY(hipStreamCreateWithFlags(&h->st_copy, hipStreamNonBlocking));
+        if (!h->st_comp) HIP_TRY(hipStreamCreateWithFlags(&h->st_comp, hipStreamNonBlocking));
+        while (h->ev_chunk.size() < n_chunks) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ev_chunk.push_back(e);
+        }
+        HIP_TRY(hipDeviceSynchronize());  // earlier null-stream work on the scratch buffers is finished
+        const uint32_t per = (B + n_chunks - 1) / n_chunks;
+        for (uint32_t c = 0, b0 = 0; b0 < B; c++, b0 += per) {
+            const uint32_t n = std::min(per, B - b0);
+            HIP_TRY(hipMemcpy2DAsync(h->s_pcm.p + (size_t)b0 * ds, ds * 2, pcm + (size_t)b0 * pcm_stride, pcm_stride * 2,
+                                     (size_t)buf_len * 2, n, hipMemcpyHostToDevice, h->st_copy));
+            HIP_TRY(hipEventRecord(h->ev_chunk[c], h->st_copy));
+            HIP_TRY(hipStreamWaitEvent(h->st_comp, h->ev_chunk[c], 0));
+            rc = sr_recognize_batch_dev(h, h->s_pcm.p + (size_t)b0 * ds, ds, buf_len, n, h->s_results.p + b0,
+                                        h->s_scores.p + (size_t)b0 * h->K,
+                                        h->s_mfcc.p + (size_t)b0 * h->cfg.max_frames * kCoef, h->s_vad.p + b0, h->st_comp);
+            if (rc) {
+                (void)hipDeviceSynchronize();
+                return rc;
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(h->st_comp));
+    }
     HIP_TRY(hipMemcpy(results, h->s_results.p, (size_t)B * sizeof(sr_result), hipMemcpyDeviceToHost));
     if (scores) HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
     if (mfcc)
