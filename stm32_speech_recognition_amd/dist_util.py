@@ -41,6 +41,38 @@ def all_gather_scores(local_scores, world, out=None):
     return out
 
 
+class ScoreExchange:
+    """Double-buffered exchange step: the all-gather of step i's scores runs on the collective's own stream while
+    the kernels of step i+1 fill the other buffer (the collective is ~1 ms of xGMI traffic next to ~33 ms of
+    kernels, but serialising it would still cost a few percent of scaling efficiency).
+
+        x = ScoreExchange(world, [gathered0, gathered1])
+        per step i:  j = i % 2;  x.reserve(j);  <kernels write local_scores[j]>;  x.launch(j, local_scores[j])
+        at the end:  x.drain()
+    reserve(j) orders the current stream after the previous collective that read local_scores[j] / wrote
+    gathered[j] (Work.wait() blocks the stream, not the host, on the nccl backend)."""
+
+    def __init__(self, world, gathered):
+        self.world = world
+        self.gathered = list(gathered)
+        self.pending = [None] * len(self.gathered)
+
+    def reserve(self, j):
+        if self.pending[j] is not None:
+            self.pending[j].wait()
+            self.pending[j] = None
+
+    def launch(self, j, local_scores):
+        if self.world == 1:
+            return
+        self.reserve(j)
+        self.pending[j] = dist.all_gather_into_tensor(self.gathered[j], local_scores.contiguous(), async_op=True)
+
+    def drain(self):
+        for j in range(len(self.pending)):
+            self.reserve(j)
+
+
 def max_over_ranks(value, device, world):
     if world == 1:
         return float(value)

@@ -42,6 +42,48 @@ def _worker(rank, world, port, B_total, K, q):
     torch.distributed.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, B_local, K, steps, q):
+    """the double-buffered exchange bench.py runs at N > 1: step i's gather is in flight while step i+1 computes"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    du.init_process_group("gloo")
+    local = [torch.empty(B_local, K, dtype=torch.int32) for _ in range(2)]
+    x = du.ScoreExchange(world, [torch.empty(world * B_local, K, dtype=torch.int32) for _ in range(2)])
+    seen = []
+    for i in range(steps):
+        j = i % 2
+        x.reserve(j)
+        if i >= 2:  # the buffer about to be overwritten holds step i-2's complete gather
+            seen.append((i - 2, x.gathered[j].numpy().view(np.uint32).copy()))
+        off = 1000 * i
+        local[j].copy_(torch.from_numpy(_fake_scores(off + rank * B_local, off + (rank + 1) * B_local, K).view(np.int32)))
+        x.launch(j, local[j])
+    x.drain()
+    for i in range(max(0, steps - 2), steps):
+        seen.append((i, x.gathered[i % 2].numpy().view(np.uint32).copy()))
+    q.put((rank, seen))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_pipelined_exchange():
+    world, B_local, K, steps = 2, 16, 6, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, B_local, K, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen in outs:
+        assert sorted(i for i, _ in seen) == list(range(steps))
+        for i, g in seen:
+            assert np.array_equal(g, _fake_scores(1000 * i, 1000 * i + world * B_local, K)), (rank, i)
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 64, 65537):
         for w in (1, 2, 3, 8):
