@@ -23,8 +23,19 @@ def main():
            "kernel,calls,avg_ns,min_ns,max_ns,pct"]
     for f in glob.glob(os.path.join(root, "stats", "*kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
-            if r["Name"].startswith("sr::"):
-                out.append(f"{r['Name']},{r['Calls']},{r['AverageNs']},{r['MinNs']},{r['MaxNs']},{r['Percentage']}")
+            if "sr::" in r["Name"]:
+                out.append(f"\"{r['Name']}\",{r['Calls']},{r['AverageNs']},{r['MinNs']},{r['MaxNs']},{r['Percentage']}")
+    # the same trace without the 100-utterance template pass (launches shorter than half the longest one are dropped):
+    # this is the per-launch duration bench.py's roofline.kernel_ms has to agree with
+    per = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, "stats", "*kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            if "sr::" in r["Kernel_Name"]:
+                per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    out += ["", "# full-batch launches only (from the kernel trace of the same run)", "kernel,full_batch_launches,avg_ns"]
+    for k, v in per.items():
+        big = [x for x in v if x > 0.5 * max(v)]
+        out.append(f"\"{k}\",{len(big)},{sum(big) / len(big):.0f}")
     out += ["", "# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <counters>), LAST full-batch launch",
             "kernel,counter,value"]
     vals, durs = {}, {}
@@ -34,7 +45,7 @@ def main():
             continue
         acc = collections.defaultdict(dict)
         for r in csv.DictReader(open(fs[0])):
-            if r["Kernel_Name"].startswith("sr::"):
+            if "sr::" in r["Kernel_Name"]:
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
                 acc[name][r["Counter_Name"]] = float(r["Counter_Value"])
                 durs[(name, r["Counter_Name"])] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])  # ns, this pass
