@@ -182,10 +182,32 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pcm, eng, out, tm, tfr, args.cpu_sample, eng_cfg)
+            if args.workload == "ref":
+                line["cpu_reference_objects"] = cpu_reference_objects(local_rank)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def usable_cores():
+    """host threads this process may really keep busy: min(affinity mask, cgroup CPU quota).  The GPU boxes expose 256
+    hardware threads but run the job under a cgroup quota (cpu.max), and oversubscribing a quota only adds throttling."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        quota = None if q == "max" else int(q) / int(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())      # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except Exception:
+            quota = None
+    if quota:
+        n = max(1, min(n, int(quota)))
+    return n, (os.cpu_count() or n), quota
 
 
 def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg):
@@ -194,7 +216,7 @@ def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg):
     cross-check the GPU results of those utterances."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    cores = os.cpu_count() or 1
+    cores, hw_threads, quota = usable_cores()
     orc = ol.Oracle(max_frames=MAX_FRAMES, **eng_cfg)
     tpl = orc.make_templates(tm, tfr.astype(np.uint32))
     host = synth.as_u16_numpy(pcm[:n])
@@ -206,8 +228,51 @@ def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg):
     gres = results_from_torch(out["results"][:n])
     match = bool(np.array_equal(gsc, osc) and np.array_equal(gres["best_tpl"], ores["best_tpl"]))
     return {"value": n / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} utterances of the timed batch, {cores} host threads, gcc -O2 oracle (tier ii)",
+            "sample": f"first {n} utterances of the timed batch, {cores} host threads (box: {hw_threads} hardware threads, "
+                      f"cgroup CPU quota {quota if quota else 'none'}), gcc -O2 oracle (tier ii)",
             "seconds": dt, "gpu_results_identical_on_sample": match}
+
+
+def cpu_reference_objects(device, n=32, Kr=100):
+    """Side figure: the reference's OWN objects (oracle/_ref: VAD.C / MFCC.C / DTW.C compiled verbatim + the C
+    transcription of the assembly FFT) timed next to the port on the largest shape they can run -- their constants are
+    compile-time, so 119 frames in a 16 000-sample capture (ADC.H:8, MFCC.H:15-16) -- single thread (file-scope
+    statics make them non-reentrant).  Shows that the port used for `cpu_baseline` is not slower than the reference's
+    code, and cross-checks the engine against the reference objects on these captures."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    if not ol.RefLib.available():
+        return None
+    T, S = 119, 16000
+    ref, orc = ol.RefLib(), ol.Oracle(max_frames=T)
+    eng = Engine(max_frames=T, device=device)
+    bank = synth.word_bank(N_WORDS)
+    rng = np.random.default_rng(7)
+    tfr = rng.integers(60, T + 1, Kr)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(Kr) % N_WORDS, tfr, seed=5, bank=bank, S=S))
+    store, st = eng.train_store(tp, np.arange(Kr), n_slots=Kr)       # save_mdl flash image (main.c:121-138)
+    assert (st == 0).all()
+    eng.set_templates_store(store)
+    words = rng.integers(0, N_WORDS, n)
+    pcm = synth.as_u16_numpy(synth.make_utterances(words, [T] * n, seed=6, bank=bank, S=S))
+    t0 = time.perf_counter()
+    r = [ref.spch_recg(pcm[b], store) for b in range(n)]               # (status, best, dis, scores, mfcc, n)
+    t_ref = time.perf_counter() - t0
+    tm = np.zeros((Kr, T + 1, 12), np.int16)
+    for k in range(Kr):
+        tm[k, :T] = store[k * 4096 + 4:k * 4096 + 4 + T * 24].view(np.int16).reshape(T, 12)
+    tpl = orc.make_templates(tm, tfr.astype(np.uint32))
+    t0 = time.perf_counter()
+    ores, _, osc = orc.recognize_batch(pcm, tpl, n_threads=1, want_mfcc=False, want_scores=True)
+    t_port = time.perf_counter() - t0
+    g = eng.recognize(pcm, want_mfcc=False, want_vad=False)
+    same = all(r[b][0] == 0 and r[b][1] == g["results"]["best_tpl"][b] == ores["best_tpl"][b]
+               and r[b][2] == g["results"]["min_dis"][b] and np.array_equal(r[b][3], g["scores"][b])
+               and np.array_equal(r[b][3], osc[b]) for b in range(n))
+    eng.close()
+    return {"shape": f"{n} captures x {Kr} templates, {T} frames, 16000-sample buffers (the reference's compile-time limits)",
+            "reference_objects_utt_per_s_1_thread": n / t_ref, "port_utt_per_s_1_thread": n / t_port,
+            "engine_reference_port_identical": bool(same)}
 
 
 if __name__ == "__main__":
