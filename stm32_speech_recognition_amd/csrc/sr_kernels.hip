@@ -48,6 +48,13 @@ __device__ __forceinline__ int sdot2a(uint32_t a, uint32_t b, int c)
 // full-rate 24-bit multiplies where the operands provably fit (quarter-rate v_mul_lo_u32 otherwise)
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+// a*b + c on the signed low 24 bits of a and b, one instruction
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // sqrtf of an integer-valued float, correctly rounded: v_sqrt_f32 is within 1 ulp; one fused-residual
 // step against the two neighbouring floats picks the correctly rounded root (the compiler's own lowering
@@ -425,14 +432,23 @@ __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__res
 __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ int8_t s_dct[kCoef * kMel];
+    __shared__ uint32_t s_dctM[kCoef * kMel];
+    __shared__ int s_dctS[kCoef * kMel];  // 32-bit: read with the wide LDS loads, no byte extraction
     __shared__ u32x4 s_tw3[8 * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
     int *xw = (int *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
     uint32_t *powb = buf + kXchgWords;
 
-    for (int i = threadIdx.x; i < kCoef * kMel; i += blockDim.x) s_dct[i] = a.t.dct[i];
+    // DCT term (MFCC.C:179): (s32)pow * dct / 100, truncated toward zero, with 0 <= pow <= 2218 (= (u32)(ln(2^32)*100))
+    // and |dct| <= 128.  floor(pow*|c|/100) == (pow * M_c) >> 18 with M_c = ceil(|c| * 2^18 / 100) for every such pair
+    // (the rounding excess pow*eps/2^18 stays below 1/100 because 100*pow < 2^18); the log stage stores pow << 14 so
+    // the quotient is one v_mul_hi_u32, and the sign of c is applied by the accumulating 24-bit multiply.
+    for (int i = threadIdx.x; i < kCoef * kMel; i += blockDim.x) {
+        const int c = a.t.dct[i];
+        s_dctM[i] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
+        s_dctS[i] = (c > 0) - (c < 0);
+    }
     __syncthreads();
 
     // ---- lane-invariant constants --------------------------------------------------------------
@@ -583,13 +599,14 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         }
 
         // ---- log (MFCC.C:165-170) and DCT (MFCC.C:173-183) for the wave's nf frames, all lanes busy
-        for (uint32_t t = lane; t < nf * kMel; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr);
+        for (uint32_t t = lane; t < nf * kMel; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
         wave_sync();
         for (uint32_t t = lane; t < nf * kCoef; t += 64) {
             const uint32_t fi = t / kCoef, h = t - fi * kCoef;
             int acc = 0;
 #pragma unroll
-            for (int i = 0; i < kMel; i++) acc += mul24((int)powb[fi * kMel + i], (int)s_dct[h * kMel + i]) / 100;
+            for (int i = 0; i < kMel; i++)
+                acc = mad24((int)__umulhi(powb[fi * kMel + i], s_dctM[h * kMel + i]), s_dctS[h * kMel + i], acc);
             out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
         }
         wave_sync();
