@@ -1045,47 +1045,73 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
         if (a.dbg_masks && lane == 0) a.dbg_masks[(uint64_t)b * 16 + (jb / 63 < 16 ? jb / 63 : 15)] = mask;
         const uint32_t nfr = (F - jb < 63u) ? F - jb : 63u;
 
-        // ---- endpoint state machine (VAD.C:164-216), wave-uniform ------------------------------
-        for (uint32_t t = 0; t < nfr; t++) {
-            const int i = (int)((jb + t) * kHop);
-            if ((mask >> t) & 1) {
-                if (cur == 0) {
+        // ---- endpoint state machine (VAD.C:164-216), wave-uniform, advanced one RUN of equal frames at a time
+        // (count-trailing-zeros on the ballot) instead of frame by frame: the scalar unit is the busiest resource
+        // of this kernel.  State and counters carry across rounds exactly as cur/front/back do in the reference.
+        //   silence(0): quiet frames do nothing; the first loud frame starts an onset with front = 1
+        //   onset(1):   each loud frame front++, the frame that makes front == v_durmin opens the segment
+        //               (start = i - (v_durmin-1)*hop, VAD.C:175-180); a quiet frame falls back to silence
+        //   speech(2):  loud frames do nothing; the first quiet frame starts a tail with back = 1
+        //   tail(3):    each quiet frame back++, the frame that makes back == s_durmax closes the segment
+        //               (end = i - s_durmax*hop + frame_len, VAD.C:198-207); a loud frame returns to speech
+        uint32_t t = 0;
+        while (t < nfr) {
+            const uint64_t rem = mask >> t, stop = 1ull << (nfr - t);  // sentinel: runs end at the round's last frame
+            const uint32_t ones = (uint32_t)__builtin_ctzll(~rem | stop), zeros = (uint32_t)__builtin_ctzll(rem | stop);
+            if (cur == 0) {
+                t += zeros;
+                if (t < nfr) {
                     cur = 1;
                     front = 1;
-                } else if (cur == 1) {
-                    front++;
-                    if (front >= v_durmin) {
-                        cur = 2;
-                        const int st = i - (int)((v_durmin - 1) * kHop);
-                        if (vcon == 0) seg0_start = st;
-                        if (lane == 0) rec_out->seg[2 * vcon] = st;
-                        front = 0;
-                    }
-                } else if (cur == 3) {
-                    back = 0;
-                    cur = 2;
+                    t++;
                 }
-            } else {
-                if (cur == 2) {
-                    cur = 3;
-                    back = 1;
-                } else if (cur == 3) {
-                    back++;
-                    if (back >= s_durmax) {
-                        cur = 0;
-                        const int en = i - (int)(s_durmax * kHop) + kFrameLen;
-                        if (vcon == 0) seg0_end = en;
-                        if (lane == 0) rec_out->seg[2 * vcon + 1] = en;
-                        vcon++;
-                        if (vcon == a.max_seg) {
-                            done = true;
-                            break;
-                        }
-                        back = 0;
-                    }
-                } else if (cur == 1) {
+            } else if (cur == 1) {
+                const uint32_t need = v_durmin - front;
+                if (ones >= need) {
+                    t += need;
+                    const int i = (int)((jb + t - 1) * kHop);  // the frame that completed the run
+                    const int st = i - (int)((v_durmin - 1) * kHop);
+                    if (vcon == 0) seg0_start = st;
+                    if (lane == 0) rec_out->seg[2 * vcon] = st;
+                    cur = 2;
+                    front = 0;
+                } else if (t + ones < nfr) {  // a quiet frame ends the onset
+                    t += ones + 1;
                     front = 0;
                     cur = 0;
+                } else {
+                    front += ones;
+                    t = nfr;
+                }
+            } else if (cur == 2) {
+                t += ones;
+                if (t < nfr) {
+                    cur = 3;
+                    back = 1;
+                    t++;
+                }
+            } else {
+                const uint32_t need = s_durmax - back;
+                if (zeros >= need) {
+                    t += need;
+                    const int i = (int)((jb + t - 1) * kHop);
+                    const int en = i - (int)(s_durmax * kHop) + kFrameLen;
+                    if (vcon == 0) seg0_end = en;
+                    if (lane == 0) rec_out->seg[2 * vcon + 1] = en;
+                    vcon++;
+                    cur = 0;
+                    back = 0;
+                    if (vcon == a.max_seg) {  // VAD.C:203-206
+                        done = true;
+                        break;
+                    }
+                } else if (t + zeros < nfr) {  // a loud frame returns to speech
+                    t += zeros + 1;
+                    back = 0;
+                    cur = 2;
+                } else {
+                    back += zeros;
+                    t = nfr;
                 }
             }
         }
