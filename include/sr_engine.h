@@ -177,12 +177,18 @@ int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_i
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
- * With profiling on, sr_recognize_batch_dev brackets each kernel with hipEvents on the launch stream;
- * sr_get_stage_ms synchronises and returns per-kernel milliseconds averaged over every call made
- * since sr_set_profiling(h, 1):  ms[0] VAD, ms[1] MFCC (frame kernel), ms[2] DTW, ms[3] argmin,
- * ms[4] whole call (first launch -> last kernel done). */
+ * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 4096 utterances each, at most
+ * SR_PIPE_MAX_CHUNKS = 8) and runs them on up to SR_PIPE_STREAMS = 4 internal streams forked from / joined to the
+ * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap (environment
+ * variables read by sr_create; SR_PIPE_STREAMS=1 keeps everything on the caller's stream).
+ * With profiling on, every kernel launch is bracketed with hipEvents on the stream it is launched on;
+ * sr_get_stage_ms synchronises and returns, averaged over everything recorded since sr_set_profiling(h, 1):
+ * ms[0] VAD, ms[1] MFCC (frame kernel), ms[2] DTW, ms[3] argmin = duration of ONE launch of that kernel (under
+ * overlap with the other chunks' kernels), ms[4] = one whole call on the caller's stream (fork -> join).
+ * sr_get_stage_launches: launches of each kernel per call (= chunks). */
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
+int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);
 
 /* diagnostics: the path's non-integer device functions swept directly:
  * out[3i] = (u32)(log((double)x)*100) (MFCC.C:168), out[3i+1] = (u32)sqrtf((float)x) (DTW.C:59),

@@ -266,7 +266,9 @@ class Engine:
     def stage_ms(self):
         ms = (C.c_float * 5)()
         self._check(self.L.sr_get_stage_ms(self.h, ms))
-        return dict(vad=ms[0], mfcc=ms[1], dtw=ms[2], argmin=ms[3], total=ms[4])
+        n = C.c_uint32(0)
+        self._check(self.L.sr_get_stage_launches(self.h, C.byref(n)))
+        return dict(vad=ms[0], mfcc=ms[1], dtw=ms[2], argmin=ms[3], total=ms[4], launches_per_call=n.value)
 
 
 def results_from_torch(t):

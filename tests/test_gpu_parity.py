@@ -200,6 +200,48 @@ def test_full_path_matches_oracle(T, B, K):
     eng.close()
 
 
+def test_chunked_multi_stream_pipeline_matches_oracle(monkeypatch):
+    """sr_recognize_batch_dev cuts large batches into chunks on internal streams; force that path at a small batch
+    (8 chunks of 96 utterances over 4 streams, ragged last chunk) and compare everything with the oracle"""
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import results_from_torch
+    monkeypatch.setenv("SR_PIPE_MIN_CHUNK", "96")
+    T, B, K = 119, 8 * 96 + 5, 10
+    bank = synth.word_bank(8)
+    orc = ol.Oracle(max_frames=T)
+    S = synth.buf_len_for(T)
+    tm, tf = _oracle_templates(orc, bank, [int(v) for v in np.random.default_rng(3).integers(60, T + 1, K)], seed=9, S=S)
+    rng = np.random.default_rng(12)
+    frames = rng.integers(40, T + 1, B)
+    pcm_t = synth.make_utterances(rng.integers(0, 8, B), frames, seed=4, bank=bank, S=S)
+    pcm = synth.as_u16_numpy(pcm_t)
+    pcm[5] = 2048  # a capture with no speech at all -> VAD fail in the middle of a chunk
+    eng = Engine(max_frames=T, device=0)
+    eng.set_templates_dense(tm, tf)
+    dev = torch.device("cuda", 0)
+    out = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
+    d_pcm = torch.from_numpy(pcm.view(np.int16)).to(dev)
+    torch.cuda.synchronize()  # the upload above ran on the default stream
+    eng.set_profiling(True)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # a non-default caller stream: fork / join must order against it
+        eng.recognize_dev(d_pcm, out)
+        res_t = out["results"].clone()
+    side.synchronize()
+    st = eng.stage_ms()
+    eng.set_profiling(False)
+    assert st["launches_per_call"] == 8 and st["total"] > 0
+    tpl = orc.make_templates(tm, tf)
+    ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
+    res = results_from_torch(res_t)
+    for f in ("best_tpl", "min_dis", "frm_num", "status"):
+        assert np.array_equal(res[f], ores[f]), f
+    assert np.array_equal(out["scores"].cpu().numpy().view(np.uint32), osc)
+    assert np.array_equal(out["mfcc"].cpu().numpy(), omf)
+    assert (ores["status"] != 0).sum() >= 1
+    eng.close()
+
+
 def test_vad_stress_matches_oracle(eng119, oracle):
     """random band-crossing activity: tight thresholds, DC steps, bursts -> exercises the block-summary
     reconstruction of last_sig (VAD.C:99,131-157) against the sample-by-sample oracle"""
