@@ -128,8 +128,17 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     dt = du.max_over_ranks(dt, dev, world)
-    stage = eng.stage_ms()  # hipEvent timings of the timed steps, on the launch stream
+    stage = eng.stage_ms()  # hipEvent timings of the timed steps, each kernel on the stream it was launched on
     eng.set_profiling(False)
+    # untimed extra: the same step as ONE chunk on one stream, for the per-kernel durations without overlap
+    eng.set_pipeline(streams=1)
+    eng.set_profiling(True)
+    for _ in range(2):
+        eng.recognize_dev(pcm, out)
+    torch.cuda.synchronize()
+    stage_iso = eng.stage_ms()
+    eng.set_profiling(False)
+    eng.set_pipeline()
     # sanity on real outputs (outside the timed region): every utterance must have exactly T frames
     res = results_from_torch(out["results"])
     assert (res["status"] == 0).all() and (res["frm_num"] == T).all(), "workload is not 256-frame utterances"
@@ -184,6 +193,7 @@ def main():
                               "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "note": "whole step (all chunks, fork -> join on the launch stream)"},
             "kernel_ms": stage,
+            "kernel_ms_isolated": {**stage_iso, "note": "untimed extra pass: whole batch as one chunk on one stream (no overlap)"},
             "top1_word_accuracy": acc,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -178,7 +178,7 @@ int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 4096 utterances each, at most
- * SR_PIPE_MAX_CHUNKS = 8) and runs them on up to SR_PIPE_STREAMS = 4 internal streams forked from / joined to the
+ * SR_PIPE_MAX_CHUNKS = 12) and runs them on SR_PIPE_STREAMS = 3 (max 4) internal streams forked from / joined to the
  * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap (environment
  * variables read by sr_create; SR_PIPE_STREAMS=1 keeps everything on the caller's stream).
  * With profiling on, every kernel launch is bracketed with hipEvents on the stream it is launched on;
@@ -186,6 +186,7 @@ int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n
  * ms[0] VAD, ms[1] MFCC (frame kernel), ms[2] DTW, ms[3] argmin = duration of ONE launch of that kernel (under
  * overlap with the other chunks' kernels), ms[4] = one whole call on the caller's stream (fork -> join).
  * sr_get_stage_launches: launches of each kernel per call (= chunks). */
+int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t max_chunks); /* same knobs at run time */
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
 int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);

@@ -87,13 +87,14 @@ struct sr_engine {
     std::vector<hipEvent_t> ev_chunk;
     // device-resident pipeline (sr_recognize_batch_dev): the batch is cut into chunks that run on a few internal
     // streams, forked from and joined back to the caller's stream, so that the kernels of different chunks overlap
-    // (k_vad / k_dtw_lds waves fill the issue slots k_mfcc leaves idle: 32.8 -> 28.0 ms per 65 536 utterances)
+    // (k_vad / k_dtw_lds waves fill the issue slots k_mfcc leaves idle: 32.0 -> 28.2 ms per 65 536 utterances)
     static constexpr uint32_t kPipeStreams = 4;
     hipStream_t st_pipe[kPipeStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kPipeStreams] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t pipe_streams = kPipeStreams;  // SR_PIPE_STREAMS (1 = one chunk on the caller's stream)
+    uint32_t pipe_streams = 3;             // SR_PIPE_STREAMS (1 = one chunk on the caller's stream); measured: 2 -> 28.8,
+                                           // 3 -> 28.2, 4 -> 30.0 ms per 65 536 utterances (1 -> 32.0)
     uint32_t pipe_min_chunk = 4096;        // SR_PIPE_MIN_CHUNK: utterances per chunk at least
-    uint32_t pipe_max_chunks = 8;          // SR_PIPE_MAX_CHUNKS
+    uint32_t pipe_max_chunks = 12;         // SR_PIPE_MAX_CHUNKS
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // 5 per kernel group (chunk): before VAD, MFCC, DTW, argmin, after argmin
     size_t ev_used = 0;          // groups recorded
@@ -174,9 +175,9 @@ int sr_create(const sr_config *cfg, sr_engine **out)
             const long x = atol(v);
             return (uint32_t)(x < (long)lo ? lo : (x > (long)hi ? hi : x));
         };
-        h->pipe_streams = env_u32("SR_PIPE_STREAMS", sr_engine::kPipeStreams, 1, sr_engine::kPipeStreams);
+        h->pipe_streams = env_u32("SR_PIPE_STREAMS", 3, 1, sr_engine::kPipeStreams);
         h->pipe_min_chunk = env_u32("SR_PIPE_MIN_CHUNK", 4096, 1, 1u << 30);
-        h->pipe_max_chunks = env_u32("SR_PIPE_MAX_CHUNKS", 8, 1, 64);
+        h->pipe_max_chunks = env_u32("SR_PIPE_MAX_CHUNKS", 12, 1, 64);
     }
     h->mfcc_tile = mfcc_frames_per_tile(h->frame_len);
     h->mfcc_grid_cap = mfcc_resident_workgroups(h->frame_len);
@@ -412,6 +413,17 @@ int sr_get_stage_ms(sr_engine *h, float ms[5])
     }
     for (int i = 0; i < 4; i++) ms[i] = (float)(acc[i] / (double)h->ev_used);
     ms[4] = (float)(acc[4] / (double)h->calls_used);
+    return SR_OK;
+}
+
+int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t max_chunks)
+{
+    if (!h) return fail(SR_ERR_BAD_ARG, "null engine");
+    if (streams < 1 || streams > sr_engine::kPipeStreams || min_chunk < 1 || max_chunks < 1 || max_chunks > 64)
+        return fail(SR_ERR_BAD_ARG, "streams 1..4, min_chunk >= 1, max_chunks 1..64");
+    h->pipe_streams = streams;
+    h->pipe_min_chunk = min_chunk;
+    h->pipe_max_chunks = max_chunks;
     return SR_OK;
 }
 
