@@ -19,7 +19,7 @@ def main():
     root, tag = sys.argv[1], sys.argv[2]
     here = os.path.dirname(os.path.abspath(__file__))
     out = [f"# rocprofv3 summary {tag}: python bench.py --steps 5 --warmup 1 --no-cpu-baseline on 1x MI355X (B=65536, K=100, T=256)",
-           "# rocprofv3 --kernel-trace --stats --output-format csv   (first k_vad/k_mfcc launch = the 100-utterance template pass)",
+           "# rocprofv3 --kernel-trace --stats --output-format csv   (all launches mixed: template pass, chunks, whole-batch pass)",
            "kernel,calls,avg_ns,min_ns,max_ns,pct"]
     for f in glob.glob(os.path.join(root, "stats", "*kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
@@ -31,12 +31,21 @@ def main():
     for f in glob.glob(os.path.join(root, "stats", "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
             if "sr::" in r["Kernel_Name"]:
-                per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-    out += ["", "# full-batch launches only (from the kernel trace of the same run)", "kernel,full_batch_launches,avg_ns"]
+                per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((float(r["Start_Timestamp"]), float(r["End_Timestamp"])))
+    out += ["", "# launches by class, from the kernel trace of the same run in dispatch order: the template pass (first k_vad /",
+            "# k_mfcc launch, 100 utterances) is dropped; 'chunk' = warm-up + timed steps (B/12 utterances per launch on three",
+            "# streams, overlapping other chunks' kernels) -- the per-launch duration bench.py's kernel_ms has to agree with;",
+            "# 'whole batch' = the last 2 launches = bench.py's untimed extra pass (one chunk, one stream)",
+            "kernel,class,launches,avg_ns"]
     for k, v in per.items():
-        big = [x for x in v if x > 0.5 * max(v)]
-        out.append(f"\"{k}\",{len(big)},{sum(big) / len(big):.0f}")
-    out += ["", "# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <counters>), LAST full-batch launch",
+        d = [e - b for b, e in sorted(v)]
+        if "k_vad" in k or "k_mfcc" in k:
+            d = d[1:]
+        chunk, whole = d[:-2], d[-2:]
+        if chunk:
+            out.append(f"\"{k}\",chunk,{len(chunk)},{sum(chunk) / len(chunk):.0f}")
+        out.append(f"\"{k}\",whole batch,{len(whole)},{sum(whole) / len(whole):.0f}")
+    out += ["", "# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <counters>), LAST launch = the whole-batch pass",
             "kernel,counter,value"]
     vals, durs = {}, {}
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
