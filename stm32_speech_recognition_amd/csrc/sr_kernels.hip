@@ -411,7 +411,8 @@ constexpr int kMfccWaves = 4;       // waves per workgroup
 constexpr int kFramesPerWave = 16;   // consecutive frames one wave turns into MFCCs per work item
 constexpr int kFramesPerTile = kMfccWaves * kFramesPerWave;
 // per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
-constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMel;  // the windowed frame aliases the exchange area
+constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMel + 64;  // the windowed frame aliases the exchange area;
+                                                                        // the last 64 words hold the odd filters' lane offsets
 
 // (u32)(log((double)n)*100), MFCC.C:168, as a step function (see sr_tables.cpp gen_log_thr).
 __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__restrict__ thr)
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
     int *xw = (int *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
-    uint32_t *powb = buf + kXchgWords;
+    uint32_t *powb = buf + kXchgWords, *moff = powb + kFramesPerWave * kMel;
 
     // DCT term (MFCC.C:179): (s32)pow * dct / 100, truncated toward zero, with 0 <= pow <= 2218 (= (u32)(ln(2^32)*100))
     // and |dct| <= 128.  floor(pow*|c|/100) == (pow * M_c) >> 18 with M_c = ceil(|c| * 2^18 / 100) for every such pair
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             }
             wave_sync();
             // ---- Mel filterbank as prefix sums over bins (each term /100 before summing, u32 wrap)
-            uint32_t pe[8], po[8];
+            uint32_t pe[8], po[8], xe, xo;
             {
                 const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
                 const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -577,22 +578,23 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                     pe[k] = se;
                     po[k] = so;
                 }
-                const uint32_t xe = wave_scan_incl(se) - se, xo = wave_scan_incl(so) - so;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    pe[k] += xe;
-                    po[k] += xo;
-                }
+                xe = wave_scan_incl(se) - se;  // sum over the bins of the lanes below
+                xo = wave_scan_incl(so) - so;
             }
             wave_sync();
+            // in-lane prefixes and the per-lane offsets are stored separately: the 24 filter lanes add them on lookup
+            // (2 adds) instead of every lane adding its offset to 16 prefixes
             *(uint4 *)(buf + 8 * lane) = make_uint4(pe[0], pe[1], pe[2], pe[3]);
             *(uint4 *)(buf + 8 * lane + 4) = make_uint4(pe[4], pe[5], pe[6], pe[7]);
             *(uint4 *)(buf + kBins + 8 * lane) = make_uint4(po[0], po[1], po[2], po[3]);
             *(uint4 *)(buf + kBins + 8 * lane + 4) = make_uint4(po[4], po[5], po[6], po[7]);
+            buf[2 * kBins + lane] = xe;
+            moff[lane] = xo;
             wave_sync();
             if (lane < kMel) {
-                const uint32_t *P = buf + ((lane & 1) ? kBins : 0);
-                const uint32_t hi = P[f_hi - 1], lo = f_lo ? P[f_lo - 1] : 0u;
+                const uint32_t *P = buf + ((lane & 1) ? kBins : 0), *X = (lane & 1) ? moff : buf + 2 * kBins;
+                const int ih = f_hi - 1, il = f_lo - 1;
+                const uint32_t hi = P[ih] + X[ih >> 3], lo = f_lo ? P[il] + X[il >> 3] : 0u;
                 powb[fi * kMel + lane] = hi - lo;
             }
             wave_sync();
