@@ -1448,6 +1448,18 @@ __device__ __forceinline__ Row32 row_from2(const u32x2 a, const u32x2 b, const u
     r.w[6] = nrm; r.w[7] = 0;
     return r;
 }
+// dst = src as four 64-bit moves (v_pk_mov_b32 moves a register pair per issue slot)
+__device__ __forceinline__ void copy_row(Row32 &dst, const Row32 &src)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        u32x2 d;
+        const u32x2 v = {src.w[i], src.w[i + 1]};
+        asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(d) : "v"(v));
+        dst.w[i] = d.x;
+        dst.w[i + 1] = d.y;
+    }
+}
 __device__ __forceinline__ int dot_rows(const Row32 &a, const Row32 &b)
 {
     int acc = sdot2z(a.w[0], b.w[0]);
@@ -1577,7 +1589,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             }
             if (adv_y) {
                 y++;
-                cm = nm;
+                copy_row(cm, nm);
                 tp += t_stride;
                 nm = row_from(tp[0], tp[1]);
             }

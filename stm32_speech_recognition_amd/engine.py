@@ -39,10 +39,11 @@ def load_library():
     """dlopen libsr_engine.so (built by __graft_entry__.build() / csrc/Makefile)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise SrError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        path = os.environ.get("SR_ENGINE_LIB", LIB_PATH)  # development override: A/B-ing two builds on one GPU box
+        if not os.path.exists(path):
+            raise SrError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.sr_last_error.restype = C.c_char_p
         L.sr_num_templates.restype = C.c_uint32
         L.sr_num_templates.argtypes = [C.c_void_p]
