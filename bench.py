@@ -165,6 +165,22 @@ def main():
                 traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]
             except Exception:
                 traffic = None
+        # what actually bounds the path: VALU issue.  Wave-level VALU instructions per utterance come from the committed
+        # PMC pass (SQ_INSTS_VALU, profiles/pmc_valu.json); every wave64 VALU instruction of this mix holds its SIMD for
+        # 4.05 cycles (SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU), so the ceiling is 1024 SIMDs * 2.4 GHz / 4 = 6.14e11 /s.
+        roofline_valu = None
+        vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if args.workload == "ref" and os.path.exists(vpath):
+            try:
+                vj = json.load(open(vpath))
+                per_utt = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
+                peak = 1024 * 2.4e9 / 4.0
+                achv = per_utt * B / (stage["total"] * 1e-3)
+                roofline_valu = {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "wave-instructions/s",
+                                 "frac": achv / peak, "valu_insts_per_utt": per_utt, "source": vj.get("source"),
+                                 "note": "derived: instruction counts from the committed PMC pass x this run's step time"}
+            except Exception:
+                roofline_valu = None
         line = {
             "metric": "utterances/sec (256-frame, 100 templates)" if args.workload == "ref"
             else "utterances/sec (EXTENSION: 16 kHz/512-pt/40 Mel, 256-frame, 500 templates; no reference counterpart)",
@@ -192,6 +208,7 @@ def main():
             "roofline_path": {"bytes_per_utt": by_path, "achieved": by_path * B / (stage["total"] * 1e-3) / 1e9,
                               "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "note": "whole step (all chunks, fork -> join on the launch stream)"},
+            "roofline_valu": roofline_valu,
             "kernel_ms": stage,
             "kernel_ms_isolated": {**stage_iso, "note": "untimed extra pass: whole batch as one chunk on one stream (no overlap)"},
             "top1_word_accuracy": acc,

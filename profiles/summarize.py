@@ -88,6 +88,14 @@ def main():
              "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM section)",
              "k_mfcc_hbm_bytes_per_launch": int((2 * fs_ + ws) * 1024)}
         json.dump(j, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
+    # VALU wave-instructions per utterance of the three big kernels (whole-batch launch, B = 65536): bench.py prices
+    # a step against the VALU issue ceiling with these
+    vj = {"source": f"profiles/{tag}_rocprof_summary.csv", "B": 65536, "counter": "SQ_INSTS_VALU (wave-level instructions)"}
+    for k in ("sr::k_vad", "sr::k_mfcc", "sr::k_dtw_lds", "sr::k_argmin"):
+        if (k, "SQ_INSTS_VALU") in vals:
+            vj[k.split("::")[1] + "_valu_insts_per_utt"] = vals[(k, "SQ_INSTS_VALU")] / 65536.0
+    if len(vj) > 3:
+        json.dump(vj, open(os.path.join(here, "pmc_valu.json"), "w"), indent=1)
     print("\n".join(out[-14:]))
 
 
