@@ -641,13 +641,18 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
 {
     using namespace ext;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ int8_t s_dct[kCoef * kMelE];
+    __shared__ uint32_t s_dctM[kCoef * kMelE];  // same exact-division-by-100 device as k_mfcc (see there)
+    __shared__ int s_dctS[kCoef * kMelE];
     __shared__ uint16_t s_hamm[kFL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *work = smem + w * kWaveWords;  // [2][256] packed samples of the even / odd sub-transform
     uint32_t *aux = work + 512;              // [2][256] pass outputs, later prefix sums
     uint32_t *powb = aux + 512;
-    for (int i = threadIdx.x; i < kCoef * kMelE; i += blockDim.x) s_dct[i] = a.t.dct[i];
+    for (int i = threadIdx.x; i < kCoef * kMelE; i += blockDim.x) {
+        const int c = a.t.dct[i];
+        s_dctM[i] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
+        s_dctS[i] = (c > 0) - (c < 0);
+    }
     for (int i = threadIdx.x; i < kFL; i += blockDim.x) s_hamm[i] = a.t.hamm[i];
     __syncthreads();
 
@@ -769,12 +774,14 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
             }
             wave_sync();
         }
-        for (uint32_t t = lane; t < nf * kMelE; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr);
+        for (uint32_t t = lane; t < nf * kMelE; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
         wave_sync();
         for (uint32_t t = lane; t < nf * kCoef; t += 64) {
             const uint32_t fi = t / kCoef, h = t - fi * kCoef;
             int acc = 0;
-            for (int i = 0; i < kMelE; i++) acc += (int)powb[fi * kMelE + i] * (int)s_dct[h * kMelE + i] / 100;
+#pragma unroll
+            for (int i = 0; i < kMelE; i++)
+                acc = mad24((int)__umulhi(powb[fi * kMelE + i], s_dctM[h * kMelE + i]), s_dctS[h * kMelE + i], acc);
             out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
         }
         wave_sync();
