@@ -1401,20 +1401,12 @@ __device__ __forceinline__ uint32_t sqrt_floor_bracket(uint32_t d, bool &unsafe)
     unsafe |= !(s0 > (float)hi);  // s0 > hi  <=>  pred(s0) >= hi  <=>  floor(pred(s0)) == hi as well
     return hi;
 }
-// three squared distances -> three (u32)sqrtf values (DTW.C:59)
-__device__ __forceinline__ void sqrt3(uint32_t &a, uint32_t &b, uint32_t &c)
+// a - b, saturating at 0
+__device__ __forceinline__ uint32_t sub_sat(uint32_t a, uint32_t b)
 {
-    bool unsafe = false;
-    const uint32_t ra = sqrt_floor_bracket(a, unsafe), rb = sqrt_floor_bracket(b, unsafe), rc = sqrt_floor_bracket(c, unsafe);
-    if (__any(unsafe)) {  // wave-uniform: a few percent of the steps
-        a = (uint32_t)sqrt_rn_int((float)a);
-        b = (uint32_t)sqrt_rn_int((float)b);
-        c = (uint32_t)sqrt_rn_int((float)c);
-    } else {
-        a = ra;
-        b = rb;
-        c = rc;
-    }
+    uint32_t r;
+    asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 __device__ __forceinline__ uint32_t dis2_from(uint32_t na, uint32_t nb, int dot) { return na + nb - 2u * (uint32_t)dot; }
 
@@ -1573,17 +1565,35 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             uint32_t d_up = (uint32_t)dot_rows_acc(nm, ci, (int)(nm.w[6] + ci.w[6]));  // (x, y+1):   get_dis(mdl+12, in)
             uint32_t d_rt = (uint32_t)dot_rows_acc(cm, ni, (int)(cm.w[6] + ni.w[6]));  // (x+1, y):   get_dis(mdl, in+12)
             uint32_t d_dg = (uint32_t)dot_rows_acc(nm, ni, (int)(nm.w[6] + ni.w[6]));  // (x+1, y+1)
-            sqrt3(d_up, d_rt, d_dg);
             const int y1 = y + 1;
             const bool in_up = (lbA <= y1) & (y1 <= ubA), in_rt = (lbB <= y) & (y <= ubB), in_dg = (lbB <= y1) & (y1 <= ubB);
-            const uint32_t up = in_up ? d_up : SR_DIS_ERR, right = in_rt ? d_rt : SR_DIS_ERR, diag = in_dg ? d_dg : SR_DIS_ERR;
             int lbN, ubN;
             column(x + 2, lbN, ubN);
-            uint32_t mn = diag;  // DTW.C:156-164
-            if (mn > right) mn = right;
-            if (mn > up) mn = up;
+            // DTW.C:152-184 on the SQUARED candidates.  g(d) = (u32)sqrtf((float)d) is monotone, so the step cost is
+            // g(min of the admissible candidates) -- one root instead of three -- and "min == right_up" / "min == up"
+            // (the tie order of DTW.C:168-184) become g(q) == g(min)  <=>  q < T, T = first d with g(d) = g(min)+1.
+            // T is (g+1)^2 up to float rounding: every q < (g+1)^2 - mg ties and every q >= (g+1)^2 + mg does not, with
+            // mg = ((g+1)^2 >> 22) + 2 (checked for every g in tests/test_oracle.py); a candidate inside that narrow
+            // band, a root of 65535 or more, or an unsafe bracket sends the wave down the exact three-root path.
+            const uint32_t q_up = in_up ? d_up : SR_DIS_ERR, q_rt = in_rt ? d_rt : SR_DIS_ERR, q_dg = in_dg ? d_dg : SR_DIS_ERR;
+            const uint32_t m2 = min(q_dg, min(q_rt, q_up));
+            bool unsafe = false;
+            uint32_t mn = sqrt_floor_bracket(m2, unsafe);
+            const uint32_t mm = mn + 1, M = umul24(mm, mm), mg = (M >> 22) + 2, lo_t = sub_sat(M, mg), hi_t = M + mg;
+            const bool tie_dg = q_dg < lo_t, tie_up = q_up < lo_t;
+            unsafe |= (m2 >= 4294836225u) | (!tie_dg & (q_dg < hi_t)) | (!tie_up & (q_up < hi_t));
+            bool mv_diag = tie_dg, mv_up = !tie_dg && tie_up;
+            if (__any(unsafe)) {  // wave-uniform; the literal form: three roots, min, equality tests
+                const uint32_t up = in_up ? (uint32_t)sqrt_rn_int((float)d_up) : SR_DIS_ERR,
+                               right = in_rt ? (uint32_t)sqrt_rn_int((float)d_rt) : SR_DIS_ERR,
+                               diag = in_dg ? (uint32_t)sqrt_rn_int((float)d_dg) : SR_DIS_ERR;
+                mn = diag;  // DTW.C:156-164
+                if (mn > right) mn = right;
+                if (mn > up) mn = up;
+                mv_diag = (mn == diag);  // DTW.C:168-184
+                mv_up = !mv_diag && (mn == up);
+            }
             dis += mn;
-            const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
             const bool adv_y = mv_diag || mv_up, adv_x = mv_diag || !mv_up;
             if (adv_x) {
                 x++;

@@ -300,6 +300,35 @@ def test_dtw_stress_matches_oracle(tpl_lo, tpl_hi):
     eng.close()
 
 
+def test_dtw_ties_and_perfect_squares_match_oracle():
+    """records whose frames differ in one or two small coefficients: the squared distances are small perfect squares
+    and sums of two squares, so candidates tie constantly and sit exactly on the (g+1)^2 boundaries the staged
+    kernel's one-root step compares against (tie order diagonal > up > right, DTW.C:168-184)"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(8)
+    maxf, K, B = 120, 50, 40
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(30, maxf, K).astype(np.uint32)
+    inf = rng.integers(40, 100, B).astype(np.uint32)
+    tm = np.zeros((K, maxf + 1, 12), np.int16)
+    im = np.zeros((B, maxf, 12), np.int16)
+    tm[:, :, 0] = rng.integers(0, 12, (K, maxf + 1))
+    im[:, :, 0] = rng.integers(0, 12, (B, maxf))
+    tm[::3, :, 5] = rng.integers(-3, 4, (len(tm[::3]), maxf + 1))
+    im[::2, :, 5] = rng.integers(-3, 4, (len(im[::2]), maxf))
+    tm[1::7, :, 0] *= 4097          # large perfect squares around and above 2^24
+    im[1::5, :, 0] *= 4097
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf)
+    sc, res = eng.dtw(im, inf)
+    pad = np.zeros((1, 12), np.int16)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
+                    dtype=np.uint32)
+    assert np.array_equal(sc, want)
+    assert (want != ol.DIS_ERR).sum() > 500
+    eng.close()
+
+
 def test_log_step_table_covers_all_steps(eng119, oracle):
     """MFCC.C:168 on the device = table of step positions built from the host's libm; cross-check the
     device path on filterbank-like magnitudes spanning 0 .. 2^32-1 via constant-spectrum frames is not

@@ -132,6 +132,34 @@ def test_get_mdl_matches_golden(oracle, golden):
     assert n == mn[p] and rows.shape[0] == 50 and np.array_equal(rows, mm[p, :50])
 
 
+def test_dtw_tie_thresholds_bracket_the_root_function(oracle):
+    """k_dtw_lds takes ONE root per step, g(min of the squared candidates), and decides the reference's tie order
+    (DTW.C:168-184) by comparing the other squared candidates with (g+1)^2 -/+ mg, mg = ((g+1)^2 >> 22) + 2.
+    That is exact iff g(q) <= g for every q < (g+1)^2 - mg and g(q) >= g+1 for every q >= (g+1)^2 + mg, with
+    g(d) = (u32)sqrtf((float)d) as in get_dis (DTW.C:59).  g is monotone, so the two boundary values per g suffice;
+    checked here for every g the kernel's fast path accepts (g <= 65534), with the C expression itself."""
+    import ctypes as C
+    r = np.arange(0, 65535, dtype=np.int64)
+    M = (r + 1) * (r + 1)
+    mg = (M >> 22) + 2
+    lo, hi = np.maximum(M - mg, 0), M + mg
+    assert hi.max() < 2 ** 32
+    sel = lo > 0
+    x = np.concatenate([(lo[sel] - 1), hi]).astype(np.uint32)
+    out = np.zeros(3 * len(x), np.uint32)
+    oracle.L.sr_oracle_math_diag(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint32(len(x)))
+    g = out[1::3].astype(np.int64)
+    n = int(sel.sum())
+    assert (g[:n] <= r[sel]).all()      # largest value the kernel calls a tie really ties
+    assert (g[n:] >= r + 1).all()       # smallest value the kernel calls "greater" really is greater
+    # and monotonicity of g itself on a dense sample around every perfect square and across the 2^24 rounding knee
+    xs = np.unique(np.clip(np.concatenate([M[::7, None] + np.arange(-3, 4)[None, :],
+                                           (2 ** 24 + np.arange(-2000, 2000))[None, :].repeat(1, 0)], axis=None), 0, 2 ** 32 - 1)).astype(np.uint32)
+    out = np.zeros(3 * len(xs), np.uint32)
+    oracle.L.sr_oracle_math_diag(xs.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint32(len(xs)))
+    assert (np.diff(out[1::3].astype(np.int64)) >= 0).all()
+
+
 def store_to_templates(store, stride=4096, tmax=120, nc=12):
     """Firmware flash image (Flash.H:11-20, MFCC.H:18-25) -> dense batched layout."""
     K = len(store) // stride
