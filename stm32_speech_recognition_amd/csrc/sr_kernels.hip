@@ -71,6 +71,8 @@ __device__ __forceinline__ float sqrt_rn_int(float f)
     return s;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ---- packed 16+16-bit helpers (VOP3P): one instruction works on the real and imaginary halves ----
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
@@ -351,7 +353,7 @@ __device__ __forceinline__ void load_tw32_d0(const u32x4 *lds, int d0, uint32_t 
 // non-zero and every imaginary part is 0.  Pass 1 (.s:226-232) then degenerates exactly to
 // out[4*idx+k] = x[bitrev8(idx)] >> 2 (k = 0..3), so it is folded into the gather.
 // lane = d0 + 4*d3 + 16*d4 ; v[d1][d2] <-> j = d0 + 4*d1 + 16*d2 + 64*d3 + 256*d4.
-__device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const LaneTw &tw, const u32x4 *tw3_lds,
+__device__ __forceinline__ void fft_front_real160(const uint16_t *xw, int lane, const LaneTw &tw, const u32x4 *tw3_lds,
                                                   uint32_t (&v)[4][4])
 {
     const int d3 = (lane >> 2) & 3, d4 = lane >> 4;
@@ -359,7 +361,7 @@ __device__ __forceinline__ void fft_front_real160(const int *xw, int lane, const
     // bitrev8(j>>2) = base + 16*rev2(d2) + 64*rev2(d1); >= 160 <=> zero padding
     uint32_t y[10];
 #pragma unroll
-    for (int m = 0; m < 10; m++) y[m] = (uint32_t)(xw[base + 16 * m] >> 2) & 0xFFFFu;
+    for (int m = 0; m < 10; m++) y[m] = xw[base + 16 * m];  // already A >> 2 as a 16-bit pattern (pass 1, .s:147-148)
 #pragma unroll
     for (int d2 = 0; d2 < 4; d2++) {
         const int r2 = ((d2 & 1) << 1) | (d2 >> 1);
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     __shared__ u32x4 s_tw3[8 * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
-    int *xw = (int *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
+    uint16_t *xw = (uint16_t *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
     uint32_t *powb = buf + kXchgWords, *moff = powb + kFramesPerWave * kMel;
 
     // DCT term (MFCC.C:179): (s32)pow * dct / 100, truncated toward zero, with 0 <= pow <= 2218 (= (u32)(ln(2^32)*100))
@@ -522,7 +524,8 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 if (i < kFrameLen) {
                     const int cur = s_cur[k] - mid, prv = s_prv[k] - mid;
                     const int t = cur - mul24(prv, 95) / 100;
-                    xw[i] = (int)(short)(mul24(t, hamm_r[k]) / 1000);
+                    // stored as the pass-1 output A >> 2 of the s16 sample (16-bit LDS store; the gather zero-extends)
+                    xw[i] = (uint16_t)((int)(short)(mul24(t, hamm_r[k]) / 1000) >> 2);
                 }
             }
             if (fi + 1 < nf) {
@@ -554,11 +557,13 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 bfly_pk<true>(u[e3][0], u[e3][1], u[e3][2], u[e3][3], k5[e3][0][0], k5[e3][0][1], k5[e3][1][0],
                               k5[e3][1][1], k5[e3][2][0], k5[e3][2][1], k5[e3][3][0], k5[e3][3][1]);
                 // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
-#pragma unroll
-                for (int o = 0; o < 2; o++) {
-                    const int r = sdot2z(u[e3][o], u[e3][o]);  // re*re + im*im straight from the packed word
-                    const uint32_t mag = (uint32_t)(sqrt_rn_int((float)r) * 10.0f);  // < 2^19
-                    buf[lane + 64 * e3 + 256 * o] = umul24(mag, mag);
+                {
+                    const float s0 = sqrt_rn_int((float)sdot2z(u[e3][0], u[e3][0]));  // re*re + im*im from the packed word
+                    const float s1 = sqrt_rn_int((float)sdot2z(u[e3][1], u[e3][1]));
+                    const f32x2 m = f32x2{s0, s1} * f32x2{10.0f, 10.0f};  // both bins in one v_pk_mul_f32 (plain IEEE multiplies)
+                    const uint32_t m0 = (uint32_t)m.x, m1 = (uint32_t)m.y;  // < 2^19
+                    buf[lane + 64 * e3] = umul24(m0, m0);
+                    buf[lane + 64 * e3 + 256] = umul24(m1, m1);
                 }
             }
             wave_sync();
