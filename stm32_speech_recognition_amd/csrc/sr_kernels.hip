@@ -72,6 +72,7 @@ __device__ __forceinline__ float sqrt_rn_int(float f)
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32_align2 __attribute__((aligned(2)));  // dword load at a 16-bit sample boundary
 
 // ---- packed 16+16-bit helpers (VOP3P): one instruction works on the real and imaginary halves ----
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -369,13 +370,14 @@ __device__ __forceinline__ void fft_front_real160(const uint16_t *xw, int lane, 
         uint32_t x2 = y[4 + r2];                                  // d1 = 2 -> rows  64..127
         uint32_t x1 = (d2 == 0) ? y[8] : (d2 == 2) ? y[9] : 0u;   // d1 = 1 -> rows 128..159, else padding
         uint32_t x3 = 0u;                                         // d1 = 3 -> rows >= 192: padding
-        // real samples: Y*conj(K) = (Yr*Kc, -Yr*Ks); tw_a = (Kc, Ks) low/high halves; D = 0 => C' = D' = C
-        const int cr = mul24(sext_lo(x2), sext_lo(tw.s2[1][0]));
-        const int ci = -mul24(sext_lo(x2), sext_hi(tw.s2[1][0]));
+        // real samples (imaginary half of the packed word is 0): the general Y*conj(K) dot products give
+        // (Yr*Kc, -Yr*Ks) directly, no sign extension needed; D = 0 => C' = D' = C
+        int cr, ci;
+        cxmul(x2, tw.s2[1][0], tw.s2[1][1], cr, ci);
         (void)x3;
         if (d2 == 0 || d2 == 2) {
-            const int br = mul24(sext_lo(x1), sext_lo(tw.s2[0][0]));
-            const int bi = -mul24(sext_lo(x1), sext_hi(tw.s2[0][0]));
+            int br, bi;
+            cxmul(x1, tw.s2[0][0], tw.s2[0][1], br, bi);
             r4_packed<false, true>(x0, br, bi, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
         } else {
             r4_packed<false, false>(x0, 0, 0, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
@@ -504,16 +506,14 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFramesPerWave) ? nfrm - f0 : (uint32_t)kFramesPerWave;
 
         // samples of frame fi+1 are requested while frame fi is transformed
-        int s_cur[3] = {0, 0, 0}, s_prv[3] = {0, 0, 0};
+        // one 2-byte-aligned dword per sample: x[i-1] in the low half, x[i] in the high half
+        uint32_t s_pp[3] = {0, 0, 0};
         if (nf) {
             const uint16_t *x = row + seg0 + (int)kHop * (int)f0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int i = lane + 64 * k;
-                if (i < kFrameLen) {
-                    s_cur[k] = x[i];
-                    s_prv[k] = x[i - 1];
-                }
+                if (i < kFrameLen) s_pp[k] = *(const u32_align2 *)(x + i - 1);
             }
         }
         for (uint32_t fi = 0; fi < nf; fi++) {
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             for (int k = 0; k < 3; k++) {
                 const int i = lane + 64 * k;
                 if (i < kFrameLen) {
-                    const int cur = s_cur[k] - mid, prv = s_prv[k] - mid;
+                    const int cur = (int)(s_pp[k] >> 16) - mid, prv = (int)(s_pp[k] & 0xFFFFu) - mid;
                     const int t = cur - mul24(prv, 95) / 100;
                     // stored as the pass-1 output A >> 2 of the s16 sample (16-bit LDS store; the gather zero-extends)
                     xw[i] = (uint16_t)((int)(short)(mul24(t, hamm_r[k]) / 1000) >> 2);
@@ -533,10 +533,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const int i = lane + 64 * k;
-                    if (i < kFrameLen) {
-                        s_cur[k] = x[i];
-                        s_prv[k] = x[i - 1];
-                    }
+                    if (i < kFrameLen) s_pp[k] = *(const u32_align2 *)(x + i - 1);
                 }
             }
             wave_sync();
