@@ -469,8 +469,10 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     int hamm_r[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
-    // triangle weights of bins 8*lane .. 8*lane+7 are re-read (L1-resident) per frame to keep registers free
-    const u32x4 *tri_e_p = (const u32x4 *)(a.t.tri_even32 + 8 * lane), *tri_o_p = (const u32x4 *)(a.t.tri_odd32 + 8 * lane);
+    // triangle weights of bins 8*lane .. 8*lane+7, packed (even | odd << 16): 8 registers for the whole kernel
+    uint32_t tri_eo[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) tri_eo[k] = a.t.tri_even32[8 * lane + k] | (a.t.tri_odd32[8 * lane + k] << 16);
     // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
     int f_lo = 0, f_hi = 0;
     if (lane < kMel) {
@@ -569,14 +571,11 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             {
                 const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
                 const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                const u32x4 te0 = tri_e_p[0], te1 = tri_e_p[1], to0 = tri_o_p[0], to1 = tri_o_p[1];
-                const uint32_t tri_e[8] = {te0.x, te0.y, te0.z, te0.w, te1.x, te1.y, te1.z, te1.w};
-                const uint32_t tri_o[8] = {to0.x, to0.y, to0.z, to0.w, to1.x, to1.y, to1.z, to1.w};
                 uint32_t se = 0, so = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    se += e[k] * tri_e[k] / 100u;
-                    so += e[k] * tri_o[k] / 100u;
+                    se += e[k] * (tri_eo[k] & 0xFFFFu) / 100u;
+                    so += e[k] * (tri_eo[k] >> 16) / 100u;
                     pe[k] = se;
                     po[k] = so;
                 }
