@@ -288,16 +288,20 @@ def cpu_reference_objects(device, n=32, Kr=100):
     eng.set_templates_store(store)
     words = rng.integers(0, N_WORDS, n)
     pcm = synth.as_u16_numpy(synth.make_utterances(words, [T] * n, seed=6, bank=bank, S=S))
-    t0 = time.perf_counter()
-    r = [ref.spch_recg(pcm[b], store) for b in range(n)]               # (status, best, dis, scores, mfcc, n)
-    t_ref = time.perf_counter() - t0
     tm = np.zeros((Kr, T + 1, 12), np.int16)
     for k in range(Kr):
         tm[k, :T] = store[k * 4096 + 4:k * 4096 + 4 + T * 24].view(np.int16).reshape(T, 12)
     tpl = orc.make_templates(tm, tfr.astype(np.uint32))
-    t0 = time.perf_counter()
-    ores, _, osc = orc.recognize_batch(pcm, tpl, n_threads=1, want_mfcc=False, want_scores=True)
-    t_port = time.perf_counter() - t0
+    # alternate the two single-thread runs and keep the best of three each: the cgroup CPU quota throttles whichever
+    # leg happens to run right after the 16-thread cpu_baseline burst
+    t_ref = t_port = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = [ref.spch_recg(pcm[b], store) for b in range(n)]               # (status, best, dis, scores, mfcc, n)
+        t_ref = min(t_ref, time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        ores, _, osc = orc.recognize_batch(pcm, tpl, n_threads=1, want_mfcc=False, want_scores=True)
+        t_port = min(t_port, time.perf_counter() - t0)
     g = eng.recognize(pcm, want_mfcc=False, want_vad=False)
     same = all(r[b][0] == 0 and r[b][1] == g["results"]["best_tpl"][b] == ores["best_tpl"][b]
                and r[b][2] == g["results"]["min_dis"][b] and np.array_equal(r[b][3], g["scores"][b])

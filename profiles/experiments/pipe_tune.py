@@ -26,7 +26,7 @@ def child():
 if len(sys.argv) > 1:
     child()
 else:
-    for st, mc, mx, mode in ((1, 4096, 8, 0), (3, 4096, 12, 0), (3, 2048, 24, 0), (3, 4096, 6, 0), (4, 4096, 12, 0), (2, 4096, 12, 0), (3, 4096, 15, 0), (3, 4096, 3, 0), (3, 4096, 12, 0)):
+    for st, mc, mx, mode in ((1, 4096, 8, 0), (3, 4096, 12, 0), (3, 4096, 9, 0), (3, 4096, 18, 0), (2, 4096, 12, 0), (3, 4096, 6, 0), (3, 2048, 30, 0), (4, 4096, 16, 0), (3, 4096, 12, 0)):
         env = dict(os.environ, SR_PIPE_STREAMS=str(st), SR_PIPE_MIN_CHUNK=str(mc), SR_PIPE_MAX_CHUNKS=str(mx), SR_PIPE_MODE=str(mode))
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         print(f"mode {mode} streams {st} min_chunk {mc} max_chunks {mx}:", r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
