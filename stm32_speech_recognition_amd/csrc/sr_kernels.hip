@@ -669,6 +669,19 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
         f_hi = (lane == kMelE - 1) ? kBinsE : (int)a.t.tri_cen[lane + 1];
     }
 
+    // coefficients of passes 2-4 (q = 4, 16, 64: blocks N = 16, 64, 256 of the ST table) are lane-invariant:
+    // loaded once, third leg also negated (see bfly_pk)
+    uint32_t kq[3][4][2];
+    {
+        int tw_base = 0;
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++) {
+            const int q = 4 << (2 * pass);
+            load_tw4(a.t, tw_base, lane & (q - 1), kq[pass]);
+            tw_base += 3 * q;
+        }
+    }
+
     for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         const uint32_t b = item / a.tiles, tile = item - b * a.tiles;
         const sr_vad_rec *rec = a.vad + b;
@@ -686,8 +699,9 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const int i = lane + 64 * k;
-                const int cur = (int)x[i] - mid, prv = (int)x[i - 1] - mid;
-                const int t = cur - prv * 95 / 100;
+                const uint32_t pp = *(const u32_align2 *)(x + i - 1);  // x[i-1] | x[i] << 16
+                const int cur = (int)(pp >> 16) - mid, prv = (int)(pp & 0xFFFFu) - mid;
+                const int t = cur - mul24(prv, 95) / 100;
                 work[(i & 1) * 256 + (i >> 1)] = (uint32_t)(t * (int)s_hamm[i] / 1000) & 0xFFFFu;
             }
 #pragma unroll
@@ -713,23 +727,21 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
             }
             wave_sync();
             // passes 2-4 (q = 4, 16, 64) in place; coefficient blocks N = 16, 64, 256 of the ST table
-            int tw_base = 0;
 #pragma unroll
-            for (int q = 4; q <= 64; q *= 4) {
+            for (int pass = 0; pass < 3; pass++) {
+                const int q = 4 << (2 * pass);
                 const int bq = lane & (q - 1), j = ((lane / q) * 4 * q) + bq;
-                uint32_t k3[3][2];
-                load_tw3(a.t, tw_base, bq, k3);
 #pragma unroll
                 for (int sub = 0; sub < 2; sub++) {
                     uint32_t *p = aux + sub * 256 + j;
                     uint32_t x0 = p[0], x1 = p[q], x2 = p[2 * q], x3 = p[3 * q];
-                    bfly(x0, x1, x2, x3, k3[0][0], k3[0][1], k3[1][0], k3[1][1], k3[2][0], k3[2][1]);
+                    bfly_pk<false>(x0, x1, x2, x3, kq[pass][0][0], kq[pass][0][1], kq[pass][1][0], kq[pass][1][1],
+                                   kq[pass][2][0], kq[pass][2][1], kq[pass][3][0], kq[pass][3][1]);
                     p[0] = x0;
                     p[q] = x1;
                     p[2 * q] = x2;
                     p[3 * q] = x3;
                 }
-                tw_base += 3 * q;
                 wave_sync();
             }
             // radix-2 pass for bins < 256: X[k] = (E[k] + O[k]*conj(W[k]) >> 14) >> 1, then |X|*10 and energy
