@@ -242,6 +242,70 @@ def test_chunked_multi_stream_pipeline_matches_oracle(monkeypatch):
     eng.close()
 
 
+def test_full_size_batch_properties():
+    """BASELINE configs[2] at its full size (65 536 utterances x 100 templates x 256 frames), checked through
+    size-independent properties: (a) chunked 3-stream execution == one chunk on one stream, bit for bit; (b) reversing
+    the batch order reverses the outputs and changes nothing else; (c) template captures mixed into the batch match
+    themselves with distance 0; (d) a strided sample of 384 utterances (first / last of every chunk included)
+    equals the oracle in MFCC, all 100 scores and argmin."""
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch
+    dev = torch.device("cuda", 0)
+    T, B, K, NW = 256, 65536, 100, 25
+    rng = np.random.default_rng(2026)
+    bank = synth.word_bank(NW)
+    eng = Engine(max_frames=320, device=0)
+    tfr = rng.integers(192, 321, K)
+    S = synth.buf_len_for(320)
+    tp = synth.make_utterances(np.arange(K) % NW, tfr, seed=77, bank=bank, S=S, device=dev)
+    tvad, tmf = eng.features_dev(tp)
+    torch.cuda.synchronize()
+    assert np.array_equal(vad_from_torch(tvad)["frm_num"], tfr)
+    tm = np.concatenate([tmf.cpu().numpy(), np.zeros((K, 1, 12), np.int16)], 1)
+    eng.set_templates_dense(tm, tfr.astype(np.uint32))
+    pcm = synth.make_utterances(rng.integers(0, NW, B), [T] * B, seed=1000, bank=bank, S=S, device=dev)
+    pcm[1000:1000 + K] = tp  # (c) the template captures themselves, same buffer length
+    out = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
+    eng.recognize_dev(pcm, out)
+    torch.cuda.synchronize()
+    res = results_from_torch(out["results"])
+    # (a)
+    eng.set_pipeline(streams=1)
+    out1 = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
+    eng.recognize_dev(pcm, out1)
+    torch.cuda.synchronize()
+    eng.set_pipeline()
+    for k in ("results", "scores", "mfcc", "vad"):
+        assert torch.equal(out[k], out1[k]), k
+    # (b)
+    rev = torch.flip(pcm, dims=[0]).contiguous()
+    eng.recognize_dev(rev, out1)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.flip(out1["results"], dims=[0]), out["results"])
+    assert torch.equal(torch.flip(out1["scores"], dims=[0]), out["scores"])
+    del rev, out1
+    # (c)
+    own = res[1000:1000 + K]
+    assert (own["status"] == 0).all() and (own["min_dis"] == 0).all() and np.array_equal(own["frm_num"], tfr)
+    sc_own = out["scores"][1000:1000 + K].cpu().numpy().view(np.uint32)
+    assert (np.diagonal(sc_own) == 0).all()
+    assert (res["status"] == 0).all()
+    # (d)
+    per = (B + 11) // 12
+    idx = sorted(set(list(range(0, B, 173))[:320] + [c * per + d for c in range(12) for d in (0, 1, per - 1) if c * per + d < B]
+                     + [1000, 1001, B - 1]))
+    sel = torch.tensor(idx, device=dev)
+    host = synth.as_u16_numpy(pcm[sel].cpu())
+    orc = ol.Oracle(max_frames=320)
+    tpl = orc.make_templates(tm, tfr.astype(np.uint32))
+    ores, omf, osc = orc.recognize_batch(host, tpl, n_threads=16)
+    assert np.array_equal(out["scores"][sel].cpu().numpy().view(np.uint32), osc)
+    assert np.array_equal(out["mfcc"][sel].cpu().numpy(), omf)
+    for f in ("best_tpl", "min_dis", "frm_num", "status"):
+        assert np.array_equal(res[f][idx], ores[f]), f
+    eng.close()
+
+
 def test_vad_stress_matches_oracle(eng119, oracle):
     """random band-crossing activity: tight thresholds, DC steps, bursts -> exercises the block-summary
     reconstruction of last_sig (VAD.C:99,131-157) against the sample-by-sample oracle"""
