@@ -177,7 +177,7 @@ int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_i
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
- * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 4096 utterances each, at most
+ * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 2048 utterances each, at most
  * SR_PIPE_MAX_CHUNKS = 12) and runs them on SR_PIPE_STREAMS = 3 (max 4) internal streams forked from / joined to the
  * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap (environment
  * variables read by sr_create; SR_PIPE_STREAMS=1 keeps everything on the caller's stream).
