@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,7 +82,6 @@ struct sr_engine {
     DevBuf<uint32_t> s_u32a, s_u32b;
     DevBuf<sr_atap> s_atap;
     DevBuf<sr_vad_rec> s_vad2;
-    // profiling: one set of 5 events per profiled call since the last sr_set_profiling(h, 1)
     // host-buffer pipeline (sr_recognize_batch): upload of chunk c+1 overlaps the kernels of chunk c
     hipStream_t st_copy = nullptr, st_comp = nullptr;
     std::vector<hipEvent_t> ev_chunk;
@@ -95,6 +95,7 @@ struct sr_engine {
                                            // 3 -> 28.2, 4 -> 30.0 ms per 65 536 utterances (1 -> 32.0)
     uint32_t pipe_min_chunk = 2048;        // SR_PIPE_MIN_CHUNK: utterances per chunk at least (smaller chunks lose more than they gain)
     uint32_t pipe_max_chunks = 12;         // SR_PIPE_MAX_CHUNKS
+    // profiling (sr_set_profiling / sr_get_stage_ms): events recorded since profiling was switched on
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // 5 per kernel group (chunk): before VAD, MFCC, DTW, argmin, after argmin
     size_t ev_used = 0;          // groups recorded
