@@ -472,6 +472,34 @@ def test_recognize_segments_matches_golden(eng119, golden):
         assert np.array_equal(sc[s_], golden["multi_scores"][:, s_])
 
 
+def test_real_speech_matches_golden(eng119):
+    """REAL speech on the GPU: capture buffers cut from the reference's own recordings and what the reference's
+    compiled objects made of them (tests/golden/real_speech.npz, make_real_golden.py): noise_atap, every VAD
+    segment, MFCC of every segment, all DTW scores, argmin -- all segments, bit for bit"""
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "real_speech.npz"))
+    eng119.set_templates_store(g["store"])
+    res, sc, vd = eng119.recognize_segments(g["pcm"])
+    assert np.array_equal(vd["seg"], g["seg"])
+    for f, col in (("mid_val", 0), ("n_thl", 1), ("z_thl", 2), ("s_thl", 3)):
+        assert np.array_equal(vd[f].astype(np.uint32), g["atap"][:, col]), f
+    for s_ in range(3):
+        assert np.array_equal(res[s_]["status"], g["status"][:, s_]), s_
+        assert np.array_equal(res[s_]["frm_num"], g["frm"][:, s_])
+        assert np.array_equal(res[s_]["min_dis"], g["dis"][:, s_])
+        assert np.array_equal(res[s_]["best_tpl"], g["best"][:, s_])
+        assert np.array_equal(sc[s_], g["scores"][:, s_])
+    # MFCC rows of every closed segment through the stage-level API
+    n = 0
+    for i in range(g["pcm"].shape[0]):
+        for s_ in range(3):
+            if g["status"][i, s_] == 0:
+                fr, m = eng119.mfcc(g["pcm"][i][None, :], np.array([g["seg"][i, 2 * s_]]), np.array([g["seg"][i, 2 * s_ + 1]]),
+                                    np.array([g["atap"][i, 0]]))
+                assert fr[0] == g["frm"][i, s_] and np.array_equal(m[0, :fr[0]], g["mfcc"][i, s_, :fr[0]]), (i, s_)
+                n += 1
+    assert n >= 20
+
+
 def test_train_store_matches_reference_layout(golden):
     """save_mdl for a batch of captures -> flash image (Flash.C:17-67), then recognise with that image"""
     from stm32_speech_recognition_amd import Engine

@@ -323,6 +323,32 @@ def test_recognize_segments_matches_golden(oracle, golden):
     assert (golden["multi_status"] == 0).sum() >= 12 and (golden["multi_status"] == 1).sum() >= 2
 
 
+def test_real_speech_matches_golden(oracle):
+    """REAL speech (capture buffers cut from the reference's own recordings, tests/golden/make_real_golden.py) through
+    the restatement vs what the reference's compiled objects made of it: noise_atap, all VAD segments, MFCC of every
+    segment, all DTW scores against a store trained from real captures, argmin"""
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "real_speech.npz"))
+    tm, tf, tv = store_to_templates(g["store"])
+    tpl = oracle.make_templates(tm, tf, tv)
+    nseg = 0
+    for i in range(g["pcm"].shape[0]):
+        rc, a = oracle.noise_atap(g["pcm"][i])
+        assert a.astuple() == tuple(int(v) for v in g["atap"][i])
+        seg = oracle.vad(g["pcm"][i], a)
+        assert np.array_equal(seg, g["seg"][i])
+        res, sc = oracle.recognize_segments(g["pcm"][i], tpl)
+        assert np.array_equal(res["status"], g["status"][i]) and np.array_equal(res["frm_num"], g["frm"][i])
+        assert np.array_equal(res["min_dis"], g["dis"][i]) and np.array_equal(res["best_tpl"], g["best"][i])
+        assert np.array_equal(sc, g["scores"][i])
+        for s_ in range(3):
+            if g["status"][i, s_] == 0:
+                n, m = oracle.mfcc(g["pcm"][i], int(seg[2 * s_]), int(seg[2 * s_ + 1]), a)
+                assert n == g["frm"][i, s_] and np.array_equal(m, g["mfcc"][i, s_, :n])
+                nseg += 1
+    assert nseg >= 20
+    assert (g["dis"][-2:, 0] == 0).all()  # the two template captures match themselves
+
+
 def expected_store_image(mfcc_rows, frames, slots, n_slots=80, stride=4096, status=None):
     """what save_ftr_mdl leaves in flash (Flash.C:17-67): erased 0xFF slot, then save_mask | frm_num | rows"""
     store = np.full(n_slots * stride, 0xFF, dtype=np.uint8)

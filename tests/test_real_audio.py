@@ -1,7 +1,7 @@
 """Real speech through both oracle tiers (CPU, only where /root/reference exists).
 
 The reference ships 13 recordings (Matlab/语音样本/*.wav, 8 kHz, 8/16-bit) and three raw 12-bit ADC dumps.
-They are read in place (never copied into this repository), converted to the ADC-like 12-bit codes the
+They are read in place, converted to the ADC-like 12-bit codes the
 firmware captures (ADC.C: 12-bit right-aligned, mid-scale ~2048) and pushed through
 noise_atap -> VAD -> get_mfcc -> dtw with the reference's own objects (tier i) and with the parametrised
 restatement (tier ii).  Everything must be bit-identical, which pins the restatement on real signals, not
