@@ -5,16 +5,24 @@
  *   Src/BSP/cr4_fft_1024_stm32.s  (ST DSP library, 1024-point radix-4 complex
  *   Q15 FFT for Cortex-M3; entry .s:219-281, butterfly macros .s:95-205,
  *   coefficient table .s:285-629).
- * The image has no ARM toolchain or emulator, so the assembly cannot be run;
- * this file follows it instruction group by instruction group.  All register
- * arithmetic is 32-bit two's complement (wraps), LDRSH sign-extends a 16-bit
- * half, STRH keeps the low 16 bits, ASR is an arithmetic (floor) shift.
+ * The image has no ARM toolchain or emulator, so the assembly cannot be run
+ * natively; this file follows it instruction group by instruction group.  All
+ * register arithmetic is 32-bit two's complement (wraps), LDRSH sign-extends a
+ * 16-bit half, STRH keeps the low 16 bits, ASR is an arithmetic (floor) shift.
  *
- * PARITY STATUS of this file: the assembly itself cannot be executed here, so
- * this restatement is "unpinned by execution".  Its evidence: the regenerated
- * coefficient table equals the .s table entry for entry, the output agrees with
- * an exact DFT/1024 within the truncation error of the five >>2 passes, and the
- * structure follows the cited instruction groups one by one.
+ * PARITY STATUS of this file: pinned by executing the reference's assembly
+ * SOURCE under oracle/arm_fft_interp.py, a small assembler + interpreter for
+ * exactly the armasm / Thumb-2 subset the .s file uses (macros expanded, the
+ * DCW table laid out, 80 336 instructions per transform).  Where
+ * /root/reference exists, tests/test_oracle.py::test_asm_fft_interpreted_
+ * equals_restatement requires bit-identical output for every committed golden
+ * input (tests/golden/ref_golden.npz: fft_in / fft_out, which is what the GPU
+ * tests compare against) and for fresh random, full-scale and zero-padded
+ * real inputs.  What remains unexecuted is real Cortex-M3 silicon: the
+ * interpreter implements the instruction semantics of the ARMv7-M manual.
+ * Further evidence: the regenerated coefficient table equals the .s table
+ * entry for entry, and the output agrees with an exact DFT/1024 within the
+ * truncation error of the five >>2 passes.
  *
  * The coefficient table is regenerated from its closed form rather than
  * pasted; tests/test_oracle_tables.py parses the table out of the .s file

@@ -37,6 +37,13 @@ def main():
         fin[i] = re.view(np.uint16).astype(np.uint32) | (im.view(np.uint16).astype(np.uint32) << 16)
     g["fft_in"] = fin
     g["fft_out"] = np.stack([r.fft(w) for w in fin])
+    # the FFT the line above ran is the C restatement of the assembly: pin the fixture to the assembly itself by
+    # interpreting the reference's .s source (oracle/arm_fft_interp.py) on the same inputs
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import arm_fft_interp
+    asm = arm_fft_interp.AsmFft()
+    for i in range(len(fin)):
+        assert np.array_equal(np.array(asm.run(fin[i])[0], dtype=np.uint32), g["fft_out"][i]), i
 
     # --- whole path on synthetic captures (T <= 119 so the verbatim objects can run them)
     bank = synth.word_bank(10)

@@ -71,6 +71,37 @@ def _pack(frame_real):
     return frame_real.view(np.uint16).astype(np.uint32)
 
 
+@needs_reference
+def test_asm_fft_interpreted_equals_restatement(golden):
+    """The reference's assembly FFT, run FROM ITS OWN SOURCE TEXT by oracle/arm_fft_interp.py (armasm / Thumb-2 subset
+    interpreter; the image has no ARM toolchain), against the C restatement and against the committed golden outputs
+    the GPU tests use.  This is what pins oracle/q15_fft.c -- and through the fixture the GPU FFT -- by execution of
+    the reference's own instructions."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import arm_fft_interp
+    m = arm_fft_interp.AsmFft(os.path.join(REFERENCE, "Src", "BSP", "cr4_fft_1024_stm32.s"))
+    assert len(m.prog) > 100 and len(m.data) == 2 * 2040     # 134 instructions after macro expansion, 3 x 340 x 2 halfwords
+    r = ol.RefLib()
+    fin, fout = golden["fft_in"], golden["fft_out"]
+    for i in range(len(fin)):                                 # every committed golden vector
+        out, steps = m.run(fin[i])
+        assert steps == 80336
+        assert np.array_equal(np.array(out, dtype=np.uint32), fout[i]), i
+    rng = np.random.default_rng(99)
+    for t in range(6):                                        # fresh inputs: random at several scales, extremes, a real frame
+        amp = [3, 700, 32767, 32767, 32767, 12000][t]
+        re = rng.integers(-amp, amp + 1, 1024).astype(np.int16)
+        im = rng.integers(-amp, amp + 1, 1024).astype(np.int16)
+        if t == 3:
+            re[:], im[:] = rng.choice([-32768, 32767], 1024), rng.choice([-32768, 32767], 1024)
+        if t == 5:
+            re[160:], im[:] = 0, 0
+        w = re.view(np.uint16).astype(np.uint32) | (im.view(np.uint16).astype(np.uint32) << 16)
+        out, _ = m.run(w)
+        assert np.array_equal(np.array(out, dtype=np.uint32), r.fft(w)), t
+
+
 def test_fft_mag_matches_golden(oracle, golden):
     """rows 16.. of the FFT fixture are zero-padded real frames, the shape fft() (MFCC.C:27-62) feeds."""
     fin, fout = golden["fft_in"], golden["fft_out"]
