@@ -715,15 +715,18 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
             for (int sub = 0; sub < 2; sub++) {
                 const uint32_t *src = work + sub * 256;
                 const int r = bitrev6(lane);
-                const uint32_t wa = src[r], wc = src[r + 64], wb = src[r + 128], wd = src[r + 192];
-                int ar = sext_lo(wa), ai = sext_hi(wa), br = sext_lo(wb), bi = sext_hi(wb);
-                int cr = sext_lo(wc), ci = sext_hi(wc), dr = sext_lo(wd), di = sext_hi(wd);
-                r4_combine<0>(ar, ai, br, bi, cr, ci, dr, di);
+                // real samples (imaginary halves 0); leg D = src[r + 192] is always zero padding (slots >= 160), so
+                // C' = D' = C.  The S = 0 combine of BUTFLY4ZERO_OPT (.s:147-168) is the packed S = 14 combine on the
+                // samples scaled by 2^14: (x << 14) >> 16 = x >> 2, (x << 14) >> 15 = x >> 1.
+                const uint32_t wa = src[r], wc = src[r + 64], wb = src[r + 128];
+                const int br = (int)(wb << 16) >> 2, cr = (int)(wc << 16) >> 2;
+                uint32_t x0, x1, x2, x3;
+                r4_packed<false, true>(wa, br, 0, cr, 0, cr, 0, x0, x1, x2, x3);
                 uint32_t *dst = aux + sub * 256 + 4 * lane;
-                dst[0] = pack16(ar, ai);
-                dst[1] = pack16(br, bi);
-                dst[2] = pack16(cr, ci);
-                dst[3] = pack16(di, dr);
+                dst[0] = x0;
+                dst[1] = x1;
+                dst[2] = x2;
+                dst[3] = x3;
             }
             wave_sync();
             // passes 2-4 (q = 4, 16, 64) in place; coefficient blocks N = 16, 64, 256 of the ST table
@@ -751,9 +754,12 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
                 const uint32_t e = aux[kb], o = aux[256 + kb];
                 int pr, pi;
                 cxmul(o, a.t.w512_a[kb], a.t.w512_b[kb], pr, pi);
-                const int re = (int)(short)((sext_lo(e) + (pr >> 14)) >> 1), im = (int)(short)((sext_hi(e) + (pi >> 14)) >> 1);
-                const int r = re * re + im * im;
-                const uint32_t mag = (uint32_t)(sqrt_rn_int((float)r) * 10.0f);
+                // (E + (P >> 14)) >> 1 == ((E << 14) + P) >> 15 (the dropped low bits of P are < 1/2); doubled once more
+                // so that the wanted 16 bits are the high halves, packed by one v_perm and squared by one dot product
+                const int t_re = (int)(((uint32_t)((int)(e << 16) >> 1)) + ((uint32_t)pr << 1));
+                const int t_im = (int)(((uint32_t)((int)(e & 0xFFFF0000u) >> 1)) + ((uint32_t)pi << 1));
+                const uint32_t xk = pk_hi16(t_re, t_im);  // (re, im) of X[k] as stored 16-bit values
+                const uint32_t mag = (uint32_t)(sqrt_rn_int((float)sdot2z(xk, xk)) * 10.0f);
                 work[kb] = mag * mag;
             }
             wave_sync();
