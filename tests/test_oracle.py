@@ -163,6 +163,19 @@ def test_get_mdl_matches_golden(oracle, golden):
     assert n == mn[p] and rows.shape[0] == 50 and np.array_equal(rows, mm[p, :50])
 
 
+def test_dct_magic_multiplier_is_exact():
+    """k_mfcc / k_mfcc_ext evaluate the DCT term (s32)pow * dct / 100 (MFCC.C:179, truncation toward zero) as
+    sign(c) * (((pow << 14) * M_c) >> 32) with M_c = ceil(|c| * 2^18 / 100).  Exhaustive over the operand ranges:
+    pow = (u32)(log(x) * 100) <= 2218 for any u32 x, c any s8."""
+    pw = np.arange(0, 2219, dtype=np.int64)[:, None]
+    c = np.arange(-128, 128, dtype=np.int64)[None, :]
+    want = np.sign(c) * ((pw * np.abs(c)) // 100)               # C division truncates toward zero
+    M = (np.abs(c) * 262144 + 99) // 100
+    got = np.sign(c) * (((pw << 14) * M) >> 32)
+    assert np.array_equal(got, want)
+    assert int(np.log(float(2 ** 32 - 1)) * 100) == 2218 and (pw.max() << 14) < 2 ** 32 and M.max() < 2 ** 24
+
+
 def test_dtw_tie_thresholds_bracket_the_root_function(oracle):
     """k_dtw_lds takes ONE root per step, g(min of the squared candidates), and decides the reference's tie order
     (DTW.C:168-184) by comparing the other squared candidates with (g+1)^2 -/+ mg, mg = ((g+1)^2 >> 22) + 2.
