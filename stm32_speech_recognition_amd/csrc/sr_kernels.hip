@@ -1398,10 +1398,13 @@ __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
 // A workgroup owns U utterances whose MFCC rows (+ squared norms) are staged in LDS once and reused by
 // all K templates; lanes are the U*K pairs ordered (template-sorted-by-length major, utterance minor),
 // so the lanes of a wave walk sequences of nearly equal length (little trip-count divergence) and
-// touch at most ceil(64/U) templates.  Templates live in HBM/L2 in an interleaved layout
-// tplT[row][ks][12] (ks = rank of the template by length), so lanes that advance in step read
-// neighbouring addresses; their squared norms are precomputed on the host (tplN[row][ks]).
-// Arithmetic is identical to dtw_pair above (same ring identities), hence bit-identical scores.
+// touch at most ceil(64/U) templates.  Templates live in HBM/L2 in a row-interleaved layout
+// tplR[row][ks] (ks = rank of the template by length) of 32-byte rows: 12 x s16 holding -2*coefficient, the
+// u32 squared norm of the row, pad -- so lanes that advance in step read neighbouring addresses and a squared
+// distance |m|^2 + |in|^2 - 2 m.in is the norm sum fed through six accumulating dot products.
+// One root per step: the root of the smallest admissible squared candidate; the reference's tie order is decided on
+// the squared values against (root+1)^2 -/+ a proven margin, with the literal three-root form as wave-uniform
+// fallback (see the loop).  The result is bit-identical to dtw_pair above.
 
 __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
 {
