@@ -1430,7 +1430,6 @@ __device__ __forceinline__ uint32_t sub_sat(uint32_t a, uint32_t b)
     asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ uint32_t dis2_from(uint32_t na, uint32_t nb, int dot) { return na + nb - 2u * (uint32_t)dot; }
 
 
 struct DtwLdsArgs {
