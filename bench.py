@@ -68,12 +68,17 @@ def main():
         N_WORDS = min(N_WORDS, K)
 
     rank, local_rank, world = du.env_rank()
+    # test hooks (tests/test_gpu_parity.py runs the N = 2 code path on a 1-GPU box): collective backend and a forced
+    # device ordinal.  The driver never sets them: N > 1 means one rank per GPU over RCCL.
+    backend = os.environ.get("SR_BENCH_BACKEND", "nccl")
+    if "SR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SR_BENCH_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        du.init_process_group("nccl", local_rank)
+        du.init_process_group(backend, local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B = args.batch

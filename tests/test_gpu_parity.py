@@ -306,6 +306,34 @@ def test_full_size_batch_properties():
     eng.close()
 
 
+def test_bench_two_ranks_end_to_end(tmp_path):
+    """bench.py's N = 2 code path end to end on this 1-GPU box: two ranks launched by torch.distributed.run share
+    device 0 and use gloo for the collectives (test hooks SR_BENCH_BACKEND / SR_BENCH_DEVICE); exercises the shards,
+    the double-buffered score exchange, barriers, max-over-ranks timing and the JSON contract"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SR_BENCH_BACKEND="gloo", SR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "4096", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["batch_per_gpu"] == 4096 and "all-gather" in j["config"]["parallelism"]
+    assert abs(j["value"] - 2 * 4096 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6
+    assert j["top1_word_accuracy"] == 1.0
+
+
 def test_vad_stress_matches_oracle(eng119, oracle):
     """random band-crossing activity: tight thresholds, DC steps, bursts -> exercises the block-summary
     reconstruction of last_sig (VAD.C:99,131-157) against the sample-by-sample oracle"""
