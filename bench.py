@@ -168,12 +168,13 @@ def main():
         # one launch covers B / launches utterances; stage[...] are per-launch durations (hipEvents on its stream)
         launches = stage["launches_per_call"]
         ach = by_mfcc * (B / launches) / (stage["mfcc"] * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:  # PMC pass measured one launch over tj["B"] utterances; a launch here covers B / launches of them
                 tj = json.load(open(tpath))
                 traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]
+                traffic_src = tj.get("source")
             except Exception:
                 traffic = None
         # what actually bounds the path: VALU issue.  Wave-level VALU instructions per utterance come from the committed
@@ -213,7 +214,7 @@ def main():
                        "batch_per_gpu": B, "templates": K, "frames": T, "buf_len": S,
                        "parallelism": f"utterance-sharded x{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_mfcc", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": by_mfcc * B / launches, "kernel_ms": stage["mfcc"],
                          "launches_per_step": launches, "utterances_per_launch": B / launches,
                          "note": "path is integer-VALU-bound, not HBM-bound (DESIGN.md); fraction reported as mandated"},
