@@ -10,7 +10,6 @@ import torch
 
 import oracle_lib as ol
 from stm32_speech_recognition_amd import synth
-from test_oracle import store_to_templates
 
 pytestmark = pytest.mark.gpu
 

@@ -10,7 +10,6 @@ import re
 
 import numpy as np
 import pytest
-import torch
 
 import oracle_lib as ol
 from conftest import REFERENCE, needs_reference

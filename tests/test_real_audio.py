@@ -11,7 +11,6 @@ import os
 import wave
 
 import numpy as np
-import pytest
 
 import oracle_lib as ol
 from conftest import REFERENCE, needs_reference
