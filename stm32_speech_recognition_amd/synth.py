@@ -78,7 +78,7 @@ def make_utterances(word_ids, frames, seed, bank, S=None, gain=1.0, head_sigma=8
         n = b1 - b0
         wid = word_ids[b0:b1]
         fr = frames[b0:b1].to(device=device, dtype=torch.float32)
-        span = (hop * (fr - 1)).unsqueeze(1)                      # speech samples
+        span = (hop * (fr - 1)).clamp(min=1).unsqueeze(1)         # speech samples (a 1-frame request has no span)
         u = ((t.unsqueeze(0) - p0) / span).clamp(0.0, 1.0)        # normalised time [n, S]
         in_word = (t.unsqueeze(0) >= p0) & (t.unsqueeze(0) < p0 + span)
         fc = f_bank[wid].to(device)                               # [n, 3, N_CTRL]

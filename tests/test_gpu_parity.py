@@ -305,6 +305,50 @@ def test_full_size_batch_properties():
     eng.close()
 
 
+@pytest.mark.parametrize("seed,maxf,K", [(1, 257, 64), (2, 119, 101), (3, 37, 3), (4, 150, 1), (5, 64, 130), (6, 16, 17)])
+def test_random_shapes_match_oracle(seed, maxf, K):
+    """seeded random engine shapes: frame cap, template count (incl. 1 and counts that leave DTW workgroups ragged),
+    batch size, utterance lengths that exceed the cap (MFCC fail), silent captures, erased slots, forced chunking"""
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 260))
+    tmax = max(2, min(maxf, 200))
+    S = synth.buf_len_for(int(tmax * 1.3) + 2)
+    bank = synth.word_bank(7)
+    orc = ol.Oracle(max_frames=maxf)
+    tfr = [int(v) for v in rng.integers(max(1, tmax // 2), tmax + 1, K)]
+    tm, tf = _oracle_templates(orc, bank, tfr, seed=seed, S=S)
+    tm = tm[:, :maxf + 1]
+    if tm.shape[1] < maxf + 1:
+        tm = np.concatenate([tm, np.zeros((K, maxf + 1 - tm.shape[1], 12), np.int16)], 1)
+    valid = (rng.random(K) > 0.1).astype(np.uint8)
+    frames = rng.integers(1, int(tmax * 1.3) + 1, B)          # some longer than the cap -> status MFCC_FAIL
+    pcm_t = synth.make_utterances(rng.integers(0, 7, B), frames, seed=50 + seed, bank=bank, S=S)
+    pcm = synth.as_u16_numpy(pcm_t)
+    for b in rng.integers(0, B, max(1, B // 20)):
+        pcm[b] = 2048 + (b % 3)                                # silent captures -> VAD fail
+    os.environ["SR_PIPE_MIN_CHUNK"] = str(int(rng.choice([7, 64, 4096])))
+    try:
+        eng = Engine(max_frames=maxf, device=0)
+    finally:
+        del os.environ["SR_PIPE_MIN_CHUNK"]
+    eng.set_templates_dense(tm, tf, valid)
+    d_pcm = torch.from_numpy(pcm.view(np.int16)).to("cuda:0")
+    out = eng.recognize_dev(d_pcm, eng.alloc_outputs(B, "cuda:0"))
+    torch.cuda.synchronize()
+    res = results_from_torch(out["results"])
+    vd = vad_from_torch(out["vad"])
+    tpl = orc.make_templates(tm, tf, valid)
+    ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
+    assert np.array_equal(vd["status"], ores["status"]), (maxf, K, B)
+    assert np.array_equal(out["mfcc"].cpu().numpy(), omf), (maxf, K, B)
+    assert np.array_equal(out["scores"].cpu().numpy().view(np.uint32), osc), (maxf, K, B)
+    for f in ("best_tpl", "min_dis", "frm_num", "status"):
+        assert np.array_equal(res[f], ores[f]), (f, maxf, K, B)
+    eng.close()
+
+
 def test_bench_two_ranks_end_to_end(tmp_path):
     """bench.py's N = 2 code path end to end on this 1-GPU box: two ranks launched by torch.distributed.run share
     device 0 and use gloo for the collectives (test hooks SR_BENCH_BACKEND / SR_BENCH_DEVICE); exercises the shards,
