@@ -211,7 +211,8 @@ constexpr uint32_t kPkPlusMinus = 0xFFFF0001u;  // (+1, -1)
 constexpr uint32_t kPkMinusPlus = 0x0001FFFFu;  // (-1, +1)
 
 // combine step on 32-bit products B, C' = C+D, D' = C-D and the packed sample A
-template <bool HALF, bool HAS_B>
+// CD_SAME: the D leg is zero, so C' = D' = C and the swapped D' halves are the C' halves rotated by 16 bits
+template <bool HALF, bool HAS_B, bool CD_SAME = false>
 __device__ __forceinline__ void r4_packed(uint32_t x0_in, int br, int bi, int sr, int si, int tr, int ti, uint32_t &x0,
                                           uint32_t &x1, uint32_t &x2, uint32_t &x3)
 {
@@ -223,11 +224,11 @@ __device__ __forceinline__ void r4_packed(uint32_t x0_in, int br, int bi, int sr
         B1 = pk_sub(pk_sub(a, hB), eB);
     }
     const uint32_t hC = pk_hi16(sr, si);
-    const uint32_t hD = pk_hi16(ti, tr);  // swapped: (D'i>>16, D'r>>16)
+    const uint32_t hD = CD_SAME ? __builtin_amdgcn_alignbit(hC, hC, 16) : pk_hi16(ti, tr);  // swapped: (D'i>>16, D'r>>16)
     x0 = pk_add(A1, hC);
     x1 = pk_mad(hD, kPkPlusMinus, B1);
     if (!HALF) {
-        const uint32_t eC = pk_bit15(sr, si), eD = pk_bit15(ti, tr);
+        const uint32_t eC = pk_bit15(sr, si), eD = CD_SAME ? __builtin_amdgcn_alignbit(eC, eC, 16) : pk_bit15(ti, tr);
         x2 = pk_sub(pk_sub(A1, hC), eC);
         x3 = pk_mad(pk_add(hD, eD), kPkMinusPlus, B1);
     }
@@ -378,9 +379,9 @@ __device__ __forceinline__ void fft_front_real160(const uint16_t *xw, int lane, 
         if (d2 == 0 || d2 == 2) {
             int br, bi;
             cxmul(x1, tw.s2[0][0], tw.s2[0][1], br, bi);
-            r4_packed<false, true>(x0, br, bi, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
+            r4_packed<false, true, true>(x0, br, bi, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
         } else {
-            r4_packed<false, false>(x0, 0, 0, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
+            r4_packed<false, false, true>(x0, 0, 0, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
         }
     }
     // pass-3 coefficients (24 words per lane) are parked in LDS, shared by the workgroup's waves
@@ -424,13 +425,12 @@ __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__res
     if (n == 0) return 0;  // log(0) = -inf -> 0 (ARM softfp and x86-64 both give 0 for the UB cast)
     int m = (int)(__log2f((float)n) * 69.31471806f);
     m = m < 0 ? 0 : (m > kLogMax ? kLogMax : m);
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        if (n < thr[m])
-            m -= 1;
-        else if (m < kLogMax && n >= thr[m + 1])
-            m += 1;
-    }
+    // v_log_f32 puts the estimate within one step of the answer for every u32 input (all 2^32 checked by
+    // tests/exhaustive_math_sweep.py), so one look at the two neighbouring thresholds settles it
+    if (n < thr[m])
+        m -= 1;
+    else if (m < kLogMax && n >= thr[m + 1])
+        m += 1;
     return (uint32_t)m;
 }
 
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
                 const uint32_t wa = src[r], wc = src[r + 64], wb = src[r + 128];
                 const int br = (int)(wb << 16) >> 2, cr = (int)(wc << 16) >> 2;
                 uint32_t x0, x1, x2, x3;
-                r4_packed<false, true>(wa, br, 0, cr, 0, cr, 0, x0, x1, x2, x3);
+                r4_packed<false, true, true>(wa, br, 0, cr, 0, cr, 0, x0, x1, x2, x3);
                 uint32_t *dst = aux + sub * 256 + 4 * lane;
                 dst[0] = x0;
                 dst[1] = x1;
