@@ -103,10 +103,15 @@ __device__ __forceinline__ uint32_t pk_hi16(int lo_src, int hi_src)
 {
     return __builtin_amdgcn_perm((uint32_t)hi_src, (uint32_t)lo_src, 0x07060302u);
 }
-// bit 15 of each source in bit 0 of the matching half: (x >> 15) = 2*(x >> 16) + this
-__device__ __forceinline__ uint32_t pk_bit15(int lo_src, int hi_src)
+// ((lo_src >> 15) & 0xFFFF , (hi_src >> 15) & 0xFFFF) -> packed word: bits 15..30 of both sources.  One plain shift
+// for the low half (its upper bits are overwritten next) and one SDWA shift that writes only word 1.
+__device__ __forceinline__ uint32_t pk_s15(int lo_src, int hi_src)
 {
-    return pk_lshr(__builtin_amdgcn_perm((uint32_t)hi_src, (uint32_t)lo_src, 0x0C050C01u), 7);
+    uint32_t r = (uint32_t)lo_src >> 15;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(r)
+        : "v"(15), "v"(hi_src));
+    return r;
 }
 
 // Orders LDS traffic between lanes of ONE wave: DS instructions of a wave execute in issue order, so
@@ -201,12 +206,14 @@ __device__ __forceinline__ void r4_combine(int &ar, int &ai, int &br, int &bi, i
 
 // One twiddled butterfly on packed words; k* = packed coefficient pairs for the legs j+q, j+2q, j+3q.
 // CXADDA4 (.s:105-129) in packed 16-bit arithmetic.  Every value the asm stores is the low 16 bits of a
-// 32-bit sum of terms (A>>2), (X>>16), (X>>15); sums mod 2^16 may be taken in any order, and
-// (X>>15) = 2*(X>>16) + bit15(X), so with h = X>>16, e = bit15(X) (both halves at once):
-//   A1 = a + hB          B1 = A1 - (B>>15) = a - hB - eB
-//   A2 = A1 + hC'        C2 = A2 - (C'>>15) = A1 - hC' - eC'
-//   B2 = B1 + S*hD'~     D2 = B2 - S*(D'>>15)~ = B1 - S*(hD'~ + eD'~)      S = (+1,-1), ~ = halves swapped
-// (.s:125-128: Br += Di>>16, Bi -= Dr>>16, Di = Br - Di>>15, Dr = Bi + Dr>>15, stored as (Di, Dr)).
+// 32-bit sum of terms (A>>2), (X>>16), (X>>15); sums mod 2^16 may be taken in any order.  With h(X) = X>>16 and
+// p(X) = X>>15 (both halves at once, mod 2^16) and (X>>15) = 2*(X>>16) + bit15(X):
+//   A1 = a + h(B)                B1 = A1 - (B>>15)                    = A1 - p(B)
+//   A2 = A1 + h(C')   = x[j]     C2 = A2 - (C'>>15)                   = x[j] - p(C')      = x[j+2q]
+//   B2 = B1 + S*h(D'~) = x[j+q]  D2 = B2 - S*(D'>>15)~                = x[j+q] - S*p(D'~) = x[j+3q]
+// S = (+1,-1), ~ = halves swapped (.s:125-128: Br += Di>>16, Bi -= Dr>>16, Di = Br - Di>>15, Dr = Bi + Dr>>15, stored
+// as (Di, Dr)).  Each ">>15" output is therefore ONE packed op on the matching ">>16" output; h() is one v_perm_b32,
+// p() a plain shift + one SDWA shift: 16 VALU for the combine of a full butterfly (19 with the bit-15 form of round 1).
 constexpr uint32_t kPkPlusMinus = 0xFFFF0001u;  // (+1, -1)
 constexpr uint32_t kPkMinusPlus = 0x0001FFFFu;  // (-1, +1)
 
@@ -219,18 +226,17 @@ __device__ __forceinline__ void r4_packed(uint32_t x0_in, int br, int bi, int sr
     const uint32_t a = pk_ashr(x0_in, 2);
     uint32_t A1 = a, B1 = a;
     if (HAS_B) {
-        const uint32_t hB = pk_hi16(br, bi), eB = pk_bit15(br, bi);
-        A1 = pk_add(a, hB);
-        B1 = pk_sub(pk_sub(a, hB), eB);
+        A1 = pk_add(a, pk_hi16(br, bi));
+        B1 = pk_sub(A1, pk_s15(br, bi));
     }
     const uint32_t hC = pk_hi16(sr, si);
     const uint32_t hD = CD_SAME ? __builtin_amdgcn_alignbit(hC, hC, 16) : pk_hi16(ti, tr);  // swapped: (D'i>>16, D'r>>16)
     x0 = pk_add(A1, hC);
     x1 = pk_mad(hD, kPkPlusMinus, B1);
     if (!HALF) {
-        const uint32_t eC = pk_bit15(sr, si), eD = CD_SAME ? __builtin_amdgcn_alignbit(eC, eC, 16) : pk_bit15(ti, tr);
-        x2 = pk_sub(pk_sub(A1, hC), eC);
-        x3 = pk_mad(pk_add(hD, eD), kPkMinusPlus, B1);
+        const uint32_t pC = pk_s15(sr, si), pD = CD_SAME ? __builtin_amdgcn_alignbit(pC, pC, 16) : pk_s15(ti, tr);
+        x2 = pk_sub(x0, pC);
+        x3 = pk_mad(pD, kPkMinusPlus, x1);
     }
 }
 
@@ -469,10 +475,13 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     int hamm_r[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
-    // triangle weights of bins 8*lane .. 8*lane+7, packed (even | odd << 16): 8 registers for the whole kernel
-    uint32_t tri_eo[8];
+    // triangle weights of bins 8*lane .. 8*lane+7 of both poly-lines: 16 registers for the whole kernel
+    uint32_t tri_e[8], tri_o[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) tri_eo[k] = a.t.tri_even32[8 * lane + k] | (a.t.tri_odd32[8 * lane + k] << 16);
+    for (int k = 0; k < 8; k++) {
+        tri_e[k] = a.t.tri_even32[8 * lane + k];
+        tri_o[k] = a.t.tri_odd32[8 * lane + k];
+    }
     // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
     int f_lo = 0, f_hi = 0;
     if (lane < kMel) {
@@ -574,8 +583,8 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 uint32_t se = 0, so = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    se += e[k] * (tri_eo[k] & 0xFFFFu) / 100u;
-                    so += e[k] * (tri_eo[k] >> 16) / 100u;
+                    se += e[k] * tri_e[k] / 100u;
+                    so += e[k] * tri_o[k] / 100u;
                     pe[k] = se;
                     po[k] = so;
                 }
