@@ -1506,6 +1506,17 @@ __device__ __forceinline__ int dot_rows_acc(const Row32 &a, const Row32 &b, int 
     return acc;
 }
 
+// rows r and r+1 of an utterance's LDS image (24-byte rows, squared norms in a separate array) into registers.
+// The six 8-byte reads are volatile so that they stay ds_read_b64 (2 LDS cycles each): merged into ds_read2_b64 they
+// cost 8 cycles a pair (MI355X_MICROARCH.md, LDS table).
+typedef __attribute__((address_space(3))) const volatile u32x2 lds_cv_u32x2;
+__device__ __forceinline__ void lds_rows2(const u32x2 *p, const uint32_t *np, Row32 &r0, Row32 &r1)
+{
+    lds_cv_u32x2 *q = (lds_cv_u32x2 *)p;  // p points into the workgroup's LDS image
+    const u32x2 a0 = q[0], a1 = q[1], a2 = q[2], b0 = q[3], b1 = q[4], b2 = q[5];
+    r0 = row_from2(a0, a1, a2, np[0]);
+    r1 = row_from2(b0, b1, b2, np[1]);
+}
 __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32x2 smem2[];  // 8-byte typed: rows are read as ds_read_b64
@@ -1559,9 +1570,11 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142
         const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
         const int c1s = 3 - ((int)in_n - 2 * (int)mdl_n), c2s = ((int)mdl_n - 2 * (int)in_n) - 3;
-        // cursors: current input row in LDS, NEXT template row in HBM; rows px+1 / py+1 always exist inside the
-        // loop (px+1 < in_n <= R and py+1 < mdl_n < tpl_rows; for 1-frame sequences row 1 is the slack row the
-        // reference's do-while reads, DTW.C:150-154)
+        // cursors: input rows x-1 / x (0-based) live in registers and are re-read from LDS only when x advances;
+        // the NEXT template row comes from HBM/L2 when y advances.  Rows x / y always exist inside the loop (x < in_n <= R
+        // and y < mdl_n < tpl_rows; for 1-frame sequences row 1 is the slack row the reference's do-while reads,
+        // DTW.C:150-154); the reload after the last advance may touch one row past the utterance's image, which the
+        // launch pads for.
         const u32x2 *in_p = smem2 + (size_t)u * (row_stride / 2);
         const uint32_t *nrm_p = s_nrm + (size_t)u * nrm_stride;
         const u32x4 *tp = a.tplR + (size_t)ks * 2;
@@ -1569,51 +1582,52 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         Row32 cm = row_from(tp[0], tp[1]);
         tp += t_stride;
         Row32 nm = row_from(tp[0], tp[1]);
-        uint32_t dis;
-        {
-            const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]);
-            dis = (uint32_t)sqrt_rn_int((float)(uint32_t)dot_rows_acc(cm, ci, (int)(cm.w[6] + ci.w[6])));  // DTW.C:146
-        }
+        Row32 ci, ni;
+        lds_rows2(in_p, nrm_p, ci, ni);
+        uint32_t dis = (uint32_t)sqrt_rn_int((float)(uint32_t)dot_rows_acc(cm, ci, (int)(cm.w[6] + ci.w[6])));  // DTW.C:146
         // dtw_limit (DTW.C:76-109) as an interval test per column: (x', y') is inside  <=>  lb(x') <= y' <= ub(x')
         //   ub(x') = x' < X1 ? 2x'+1 : (x'+3-c1) >> 1      (negation of DTW.C:78-91; >> floors)
         //   lb(x') = x' < X2 ? x' >> 1 : 2x'+c2-3           (negation of DTW.C:93-106)
-        // The bounds of columns x (A) and x+1 (B) are carried; one new column is evaluated per step.
-        auto column = [&](int xx, int &lb, int &ub) {
-            ub = (xx < X1) ? 2 * xx + 1 : ((xx + c1s) >> 1);
-            lb = (xx < X2) ? (xx >> 1) : 2 * xx + c2s;
-        };
-        int x = 1, y = 1;  // DTW.C:147-148
-        int lbA, ubA, lbB, ubB;
-        column(1, lbA, ubA);
-        column(2, lbB, ubB);
+        // Carried: ub of column x (A), lb and ub of column x+1 (B); one new column is evaluated when x advances.
+        // lb(x) is not needed: the walk only ever moves to admissible points, so lb(x) <= y holds for the current point
+        // and (x, y+1) can only leave through ub(x).  The one exception -- all three candidates outside, DTW.C:156-184
+        // then moves diagonally to an outside point -- makes the lane `lost`: from then on it takes the literal path.
+        auto ub_of = [&](int xx) { return (xx < X1) ? 2 * xx + 1 : ((xx + c1s) >> 1); };
+        auto lb_of = [&](int xx) { return (xx < X2) ? (xx >> 1) : 2 * xx + c2s; };
+        int xB = 2, y = 1;  // xB = x + 1; DTW.C:147-148
+        int ubA = ub_of(1), lbB = lb_of(2), ubB = ub_of(2);
+        bool lost = false;
         uint32_t step = 1;  // u16 in the reference; cannot wrap here (steps < in_n + mdl_n <= 2R, R bounded by LDS)
         do {
-            const Row32 ci = row_from2(in_p[0], in_p[1], in_p[2], nrm_p[0]),
-                        ni = row_from2(in_p[3], in_p[4], in_p[5], nrm_p[1]);
             // all three candidate squared distances, unconditionally: |m|^2 + |i|^2 + (-2m).i, the norm sum seeds
             // the dot2 accumulator (template rows are stored as -2m, see upload_templates)
-            uint32_t d_up = (uint32_t)dot_rows_acc(nm, ci, (int)(nm.w[6] + ci.w[6]));  // (x, y+1):   get_dis(mdl+12, in)
-            uint32_t d_rt = (uint32_t)dot_rows_acc(cm, ni, (int)(cm.w[6] + ni.w[6]));  // (x+1, y):   get_dis(mdl, in+12)
-            uint32_t d_dg = (uint32_t)dot_rows_acc(nm, ni, (int)(nm.w[6] + ni.w[6]));  // (x+1, y+1)
+            const uint32_t d_up = (uint32_t)dot_rows_acc(nm, ci, (int)(nm.w[6] + ci.w[6]));  // (x, y+1):   get_dis(mdl+12, in)
+            const uint32_t d_rt = (uint32_t)dot_rows_acc(cm, ni, (int)(cm.w[6] + ni.w[6]));  // (x+1, y):   get_dis(mdl, in+12)
+            const uint32_t d_dg = (uint32_t)dot_rows_acc(nm, ni, (int)(nm.w[6] + ni.w[6]));  // (x+1, y+1)
             const int y1 = y + 1;
-            const bool in_up = (lbA <= y1) & (y1 <= ubA), in_rt = (lbB <= y) & (y <= ubB), in_dg = (lbB <= y1) & (y1 <= ubB);
-            int lbN, ubN;
-            column(x + 2, lbN, ubN);
+            bool in_up = (y1 <= ubA), in_rt = (lbB <= y) & (y <= ubB), in_dg = (lbB <= y1) & (y1 <= ubB);
             // DTW.C:152-184 on the SQUARED candidates.  g(d) = (u32)sqrtf((float)d) is monotone, so the step cost is
             // g(min of the admissible candidates) -- one root instead of three -- and "min == right_up" / "min == up"
             // (the tie order of DTW.C:168-184) become g(q) == g(min)  <=>  q < T, T = first d with g(d) = g(min)+1.
             // T is (g+1)^2 up to float rounding: every q < (g+1)^2 - mg ties and every q >= (g+1)^2 + mg does not, with
-            // mg = ((g+1)^2 >> 22) + 2 (checked for every g in tests/test_oracle.py); a candidate inside that narrow
-            // band, a root of 65535 or more, or an unsafe bracket sends the wave down the exact three-root path.
+            // mg = ((g+1)^2 >> 22) + 2 (checked for every g in tests/test_oracle.py); a candidate inside that narrow band,
+            // a root of 65535 or more (which includes "all three outside"), an unsafe bracket or a lost lane sends the wave
+            // down the literal three-root path.  The margin has to stay this tight: neighbouring frames are similar, so the
+            // three candidates lie close together and a constant margin of 18 already put 4 % of the wave-steps on the
+            // literal path (258: half of them).
             const uint32_t q_up = in_up ? d_up : SR_DIS_ERR, q_rt = in_rt ? d_rt : SR_DIS_ERR, q_dg = in_dg ? d_dg : SR_DIS_ERR;
             const uint32_t m2 = min(q_dg, min(q_rt, q_up));
-            bool unsafe = false;
+            bool unsafe = lost;
             uint32_t mn = sqrt_floor_bracket(m2, unsafe);
             const uint32_t mm = mn + 1, M = umul24(mm, mm), mg = (M >> 22) + 2, lo_t = sub_sat(M, mg), hi_t = M + mg;
             const bool tie_dg = q_dg < lo_t, tie_up = q_up < lo_t;
             unsafe |= (m2 >= 4294836225u) | (!tie_dg & (q_dg < hi_t)) | (!tie_up & (q_up < hi_t));
             bool mv_diag = tie_dg, mv_up = !tie_dg && tie_up;
-            if (__any(unsafe)) {  // wave-uniform; the literal form: three roots, min, equality tests
+            if (__builtin_amdgcn_ballot_w64(unsafe) != 0ull) {  // wave-uniform; the literal form: dtw_limit on the three points, three roots, min, equality tests
+                const int x = xB - 1;
+                in_up = !dtw_out(x, y1, X1, X2, (int)in_n, (int)mdl_n);
+                in_rt = !dtw_out(xB, y, X1, X2, (int)in_n, (int)mdl_n);
+                in_dg = !dtw_out(xB, y1, X1, X2, (int)in_n, (int)mdl_n);
                 const uint32_t up = in_up ? (uint32_t)sqrt_rn_int((float)d_up) : SR_DIS_ERR,
                                right = in_rt ? (uint32_t)sqrt_rn_int((float)d_rt) : SR_DIS_ERR,
                                diag = in_dg ? (uint32_t)sqrt_rn_int((float)d_dg) : SR_DIS_ERR;
@@ -1622,17 +1636,18 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 if (mn > up) mn = up;
                 mv_diag = (mn == diag);  // DTW.C:168-184
                 mv_up = !mv_diag && (mn == up);
+                lost |= !(in_up | in_rt | in_dg);
             }
             dis += mn;
             const bool adv_y = mv_diag || mv_up, adv_x = mv_diag || !mv_up;
             if (adv_x) {
-                x++;
+                xB++;
                 in_p += 3;
                 nrm_p++;
-                lbA = lbB;
+                lds_rows2(in_p, nrm_p, ci, ni);
                 ubA = ubB;
-                lbB = lbN;
-                ubB = ubN;
+                ubB = ub_of(xB);
+                lbB = lb_of(xB);
             }
             if (adv_y) {
                 y++;
@@ -1641,7 +1656,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 nm = row_from(tp[0], tp[1]);
             }
             step++;
-        } while (x < (int)in_n && y < (int)mdl_n);  // DTW.C:188
+        } while (xB <= (int)in_n && y < (int)mdl_n);  // DTW.C:188 (x < in)
         score = dis / step;
     }
     a.d.scores[(size_t)b * K + a.tpl_orig[ks]] = score;
@@ -1660,7 +1675,7 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes)
         const uint64_t pairs = (uint64_t)U * K;
         if (pairs > 1024) break;
         const size_t lds = U * per_u;
-        if (lds > 150 * 1024) break;
+        if (lds + 64 > 150 * 1024) break;
         const uint32_t waves = (uint32_t)((pairs + 63) / 64);
         uint32_t blocks = (uint32_t)((160 * 1024) / (lds + 512));
         if (blocks > 32 / waves) blocks = 32 / waves;
@@ -1675,7 +1690,7 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes)
             best_u = U;
         }
     }
-    if (best_u && lds_bytes) *lds_bytes = best_u * per_u;
+    if (best_u && lds_bytes) *lds_bytes = best_u * per_u + 64;  // + slack: the last reload may read one row / norm past the image
     return best_u;
 }
 
