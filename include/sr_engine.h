@@ -94,6 +94,21 @@ int sr_create(const sr_config *cfg, sr_engine **out);
 void sr_destroy(sr_engine *h);
 const char *sr_last_error(void); /* thread-local text of the last failure */
 
+/* Host-only (touches no device): the constant tables sr_create generates for cfg, for inspection and for
+ * diffing against the reference's pasted tables (MFCC_Arg.h:6-44: hamm, tri_cen, tri_odd, tri_even, dct_arg;
+ * cr4_fft_1024_stm32.s:285-629: the (Kr', Ki) coefficient columns).  Every pointer may be NULL. */
+typedef struct sr_tables {
+    uint16_t *hamm;     /* [frame_len]       hamm[],    MFCC_Arg.h:6-9 */
+    uint16_t *tri_cen;  /* [n_mel]           tri_cen[], MFCC_Arg.h:11-15 */
+    uint16_t *tri_even; /* [nfft / 2]        tri_even[] */
+    uint16_t *tri_odd;  /* [nfft / 2]        tri_odd[] */
+    int8_t *dct;        /* [n_coef * n_mel]  dct_arg[] */
+    int16_t *tw_kr;     /* [1020]            first  DCW column of the ST coefficient table, in table order */
+    int16_t *tw_ki;     /* [1020]            second DCW column */
+    uint32_t *log_thr;  /* [2220]            log_thr[m] = min{n : (u32)(log((double)n)*100) >= m} (host libm), [2219] = sentinel */
+} sr_tables;
+int sr_build_tables(const sr_config *cfg, const sr_tables *out);
+
 /* ------------------------------------------------------------------ template store
  * The firmware keeps templates as v_ftr_tag images in MCU flash at a 4 KiB stride
  * (Flash.H:11-20, MFCC.H:18-25: u16 save_sign | u16 frm_num | s16 mfcc[]), and

@@ -28,6 +28,32 @@ static int fail(int code, const std::string &msg)
             return fail(SR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
 
+
+// Every entry point runs on the engine's device and puts the caller's current device back afterwards (a
+// single-process multi-GPU caller -- or PyTorch on another ordinal -- keeps its own current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool restore = false;
+    int enter(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        hipError_t e = hipSetDevice(dev);
+        if (e != hipSuccess) return fail(SR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        restore = prev >= 0 && prev != dev;
+        return SR_OK;
+    }
+    ~DeviceGuard()
+    {
+        if (restore) (void)hipSetDevice(prev);
+    }
+};
+#define ENTER_DEVICE(h)                      \
+    DeviceGuard dev_guard_;                  \
+    do {                                     \
+        int rc_dev_ = dev_guard_.enter((h)->device); \
+        if (rc_dev_) return rc_dev_;         \
+    } while (0)
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -140,18 +166,46 @@ void sr_default_config(sr_config *c)
     c->device = -1;
 }
 
-int sr_create(const sr_config *cfg, sr_engine **out)
+// Two front ends are built: the reference's (8 kHz, 160/80 framing, 1024-point FFT, 24 Mel) and the
+// 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
+static int front_end_of(const sr_config *cfg, FrontEnd *fe)
 {
-    if (!cfg || !out) return fail(SR_ERR_BAD_ARG, "null argument");
-    *out = nullptr;
-    // Two front ends are built: the reference's (8 kHz, 160/80 framing, 1024-point FFT, 24 Mel) and the
-    // 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
     const bool is_ref = cfg->fs == 8000 && cfg->nfft == 1024 && cfg->n_mel == 24;
     const bool is_ext = cfg->fs == 16000 && cfg->nfft == 512 && cfg->n_mel == 40;
     if (!(is_ref || is_ext) || cfg->frame_time_ms != 20 || cfg->frame_mov_ms != 10 || cfg->n_coef != 12)
         return fail(SR_ERR_BAD_CONFIG,
                     "supported: fs=8000/nfft=1024/24 Mel (reference) or fs=16000/nfft=512/40 Mel (extension), 20/10 ms, 12 MFCC");
-    const FrontEnd fe = is_ext ? kFrontExt : kFrontRef;
+    *fe = is_ext ? kFrontExt : kFrontRef;
+    return SR_OK;
+}
+
+// Host-only: the tables sr_create would upload for cfg, copied out for inspection (tests diff them against
+// MFCC_Arg.h:6-44 and cr4_fft_1024_stm32.s:285-629).  No device is touched.
+int sr_build_tables(const sr_config *cfg, const sr_tables *out)
+{
+    if (!cfg || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    FrontEnd fe;
+    int rc = front_end_of(cfg, &fe);
+    if (rc) return rc;
+    HostTables t;
+    build_tables(t, fe);
+    if (out->hamm) std::memcpy(out->hamm, t.hamm.data(), t.hamm.size() * 2);
+    if (out->tri_cen) std::memcpy(out->tri_cen, t.tri_cen.data(), t.tri_cen.size() * 2);
+    if (out->tri_even) std::memcpy(out->tri_even, t.tri_even.data(), t.tri_even.size() * 2);
+    if (out->tri_odd) std::memcpy(out->tri_odd, t.tri_odd.data(), t.tri_odd.size() * 2);
+    if (out->dct) std::memcpy(out->dct, t.dct.data(), t.dct.size());
+    if (out->tw_kr) std::memcpy(out->tw_kr, t.tw_kr.data(), t.tw_kr.size() * 2);
+    if (out->tw_ki) std::memcpy(out->tw_ki, t.tw_ki.data(), t.tw_ki.size() * 2);
+    if (out->log_thr) std::memcpy(out->log_thr, t.log_thr.data(), t.log_thr.size() * 4);
+    return SR_OK;
+}
+
+int sr_create(const sr_config *cfg, sr_engine **out)
+{
+    if (!cfg || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    FrontEnd fe;
+    if (int rcf = front_end_of(cfg, &fe)) return rcf;
     if (cfg->max_frames < 2 || cfg->max_frames > 16383) return fail(SR_ERR_BAD_CONFIG, "max_frames must be 2..16383");
     if (cfg->max_seg < 1 || cfg->max_seg > SR_MAX_SEG) return fail(SR_ERR_BAD_CONFIG, "max_seg must be 1..3");
     const uint32_t noise_len = (cfg->fs / 1000) * cfg->noise_len_ms, atap_frm = (cfg->fs / 1000) * 30;
@@ -160,7 +214,8 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     int dev = 0;
     int rc = check_device(cfg->device, &dev);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(dev));
+    DeviceGuard dev_guard_;
+    if ((rc = dev_guard_.enter(dev))) return rc;
 
     sr_engine *h = new sr_engine();
     h->cfg = *cfg;
@@ -229,7 +284,9 @@ int sr_create(const sr_config *cfg, sr_engine **out)
 void sr_destroy(sr_engine *h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dev_guard_;
+    (void)dev_guard_.enter(h->device);
+    (void)hipDeviceSynchronize();
     if (h->table_blob) (void)hipFree(h->table_blob);
     h->tpl.release();
     h->tpl_frames.release();
@@ -262,19 +319,28 @@ void sr_destroy(sr_engine *h)
 uint32_t sr_num_templates(const sr_engine *h) { return h ? h->K : 0; }
 
 // ---- template store -------------------------------------------------------------------------------
+// Builds the new store in fresh device buffers and publishes it (pointers, K, rows, kernel geometry) only after every
+// upload has succeeded, so a failure leaves the previous store intact.  The call first waits for all work on the device:
+// the internal pipeline streams and user streams are non-blocking, and a kernel of an earlier asynchronous
+// sr_recognize_batch_dev may still be reading the old rows.
 static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const std::vector<uint32_t> &f,
                             const std::vector<uint8_t> &v, uint32_t K, uint32_t rows)
 {
-    HIP_TRY(hipSetDevice(h->device));
-    int rc;
-    if ((rc = h->tpl.reserve(m.size()))) return rc;
-    if ((rc = h->tpl_frames.reserve(K))) return rc;
-    if ((rc = h->tpl_valid.reserve(K))) return rc;
-    HIP_TRY(hipMemcpy(h->tpl.p, m.data(), m.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tpl_frames.p, f.data(), K * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->tpl_valid.p, v.data(), K, hipMemcpyHostToDevice));
-    // length-sorted, row-interleaved copy + squared norms for the LDS-staged DTW kernel
-    {
+    ENTER_DEVICE(h);
+    HIP_TRY(hipDeviceSynchronize());
+    DevBuf<int16_t> n_tpl;
+    DevBuf<uint32_t> n_frames, n_tplR, n_frames_s, n_orig;
+    DevBuf<uint8_t> n_valid;
+    bool fits = true;
+    auto build = [&]() -> int {
+        int rc;
+        if ((rc = n_tpl.reserve(m.size()))) return rc;
+        if ((rc = n_frames.reserve(K))) return rc;
+        if ((rc = n_valid.reserve(K))) return rc;
+        HIP_TRY(hipMemcpy(n_tpl.p, m.data(), m.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(n_frames.p, f.data(), K * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(n_valid.p, v.data(), K, hipMemcpyHostToDevice));
+        // length-sorted, row-interleaved copy + squared norms for the LDS-staged DTW kernel
         std::vector<uint32_t> order(K);
         for (uint32_t k = 0; k < K; k++) order[k] = k;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
@@ -285,7 +351,6 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
         // norm sum seeding the v_dot2 accumulator.  -2*coef must fit s16: coefficients outside [-16383, 16384]
         // (unreachable for log-Mel cepstra, reachable for arbitrary s16 records) disable the staged kernel for
         // this store and the generic k_dtw, which makes no such assumption, scores it.
-        bool fits = true;
         std::vector<uint32_t> rt((size_t)rows * K * 8, 0u), fs(K);
         for (uint32_t ks = 0; ks < K; ks++) {
             const uint32_t k = order[ks];
@@ -304,14 +369,37 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
                 dst[6] = nrm;
             }
         }
-        h->tpl_staged_ok = fits;
-        if ((rc = h->tplR.reserve(rt.size()))) return rc;
-        if ((rc = h->tpl_frames_s.reserve(K))) return rc;
-        if ((rc = h->tpl_orig.reserve(K))) return rc;
-        HIP_TRY(hipMemcpy(h->tplR.p, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->tpl_frames_s.p, fs.data(), K * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->tpl_orig.p, order.data(), K * 4, hipMemcpyHostToDevice));
+        if ((rc = n_tplR.reserve(rt.size()))) return rc;
+        if ((rc = n_frames_s.reserve(K))) return rc;
+        if ((rc = n_orig.reserve(K))) return rc;
+        HIP_TRY(hipMemcpy(n_tplR.p, rt.data(), rt.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(n_frames_s.p, fs.data(), K * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(n_orig.p, order.data(), K * 4, hipMemcpyHostToDevice));
+        return SR_OK;
+    };
+    const int rc = build();
+    if (rc) {  // previous store untouched
+        n_tpl.release();
+        n_frames.release();
+        n_valid.release();
+        n_tplR.release();
+        n_frames_s.release();
+        n_orig.release();
+        return rc;
     }
+    std::swap(h->tpl, n_tpl);
+    std::swap(h->tpl_frames, n_frames);
+    std::swap(h->tpl_valid, n_valid);
+    std::swap(h->tplR, n_tplR);
+    std::swap(h->tpl_frames_s, n_frames_s);
+    std::swap(h->tpl_orig, n_orig);
+    n_tpl.release();  // the old store (nothing in flight: synchronised above)
+    n_frames.release();
+    n_valid.release();
+    n_tplR.release();
+    n_frames_s.release();
+    n_orig.release();
+    h->tpl_staged_ok = fits;
     {
         size_t lds = 0;
         h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds) : 0;
@@ -366,6 +454,7 @@ int sr_set_templates(sr_engine *h, const void *store, uint32_t n_slots, uint32_t
         f[k] = fr;
         if (v[k]) {
             if (fr > slot_rows) return fail(SR_ERR_BAD_ARG, "slot frm_num exceeds the slot size");
+            if (fr > 16383) return fail(SR_ERR_BAD_ARG, "template longer than 16383 frames");
             maxf = fr > maxf ? fr : maxf;
         }
     }
@@ -383,7 +472,7 @@ int sr_set_templates(sr_engine *h, const void *store, uint32_t n_slots, uint32_t
 int sr_set_profiling(sr_engine *h, int on)
 {
     if (!h) return fail(SR_ERR_BAD_ARG, "null engine");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     h->profiling = on != 0;
     h->ev_used = 0;
     h->calls_used = 0;
@@ -437,6 +526,12 @@ int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call)
 }
 
 // ---- device-resident pipeline ---------------------------------------------------------------------
+// the frame kernel indexes (utterance, tile) work items with 32 bits
+static int check_batch(const sr_engine *h, uint32_t B)
+{
+    if ((uint64_t)B * ((h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
+    return SR_OK;
+}
 static int check_pcm(const sr_engine *h, const uint16_t *pcm, uint64_t stride, uint32_t buf_len)
 {
     if (!pcm) return fail(SR_ERR_BAD_ARG, "null pcm");
@@ -453,7 +548,7 @@ int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, u
     if (!h || !d_vad) return fail(SR_ERR_BAD_ARG, "null argument");
     int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     VadArgs a{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr, h->frame_len};
     launch_vad(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -482,8 +577,8 @@ int sr_mfcc_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, 
                       int16_t *d_mfcc, void *stream)
 {
     if (!h || !d_pcm || !d_vad || !d_mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
-    if ((uint64_t)B * ((h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
-    HIP_TRY(hipSetDevice(h->device));
+    if (int rcb = check_batch(h, B)) return rcb;
+    ENTER_DEVICE(h);
     launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, d_vad, d_mfcc), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SR_OK;
@@ -519,7 +614,7 @@ int sr_dtw_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_va
 {
     if (!h || !d_mfcc || !d_vad || !d_scores) return fail(SR_ERR_BAD_ARG, "null argument");
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     DtwArgs a = dtw_args(h, d_mfcc, d_vad, nullptr, B, d_scores, d_results);
     launch_dtw(a, (hipStream_t)stream);
     if (d_results) launch_argmin(a, (hipStream_t)stream);
@@ -535,8 +630,8 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
     if (B == 0) return SR_OK;
     int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
     if (rc) return rc;
-    if ((uint64_t)B * ((h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile) > 0xFFFFFFFFull) return fail(SR_ERR_BAD_ARG, "batch too large");
-    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = check_batch(h, B))) return rc;
+    ENTER_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     if (!d_vad) {
         if ((rc = h->s_vad.reserve(B))) return rc;
@@ -624,7 +719,8 @@ int sr_recognize_segments_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_
     if (B == 0) return SR_OK;
     int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = check_batch(h, B))) return rc;
+    ENTER_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     if (!d_vad) {
         if ((rc = h->s_vad.reserve(B))) return rc;
@@ -672,7 +768,7 @@ int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
     if (B == 0) return SR_OK;
     if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     const uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
     int rc;
     if ((rc = h->s_pcm.reserve((size_t)B * ds))) return rc;
@@ -731,7 +827,7 @@ int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
     if (B == 0) return SR_OK;
     if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     const uint32_t ms = h->cfg.max_seg;
     uint64_t ds = 0;
     int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
@@ -752,7 +848,7 @@ int sr_vad_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_
     if (!h || !pcm || !vad) return fail(SR_ERR_BAD_ARG, "null argument");
     if (B == 0) return SR_OK;
     if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     uint64_t ds = 0;
     int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
     if (rc) return rc;
@@ -767,10 +863,13 @@ int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
                        sr_vad_rec *vad, uint64_t *masks /* [B][16] */)
 {
     if (!h || !pcm || !vad || !masks) return fail(SR_ERR_BAD_ARG, "null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    if (B == 0) return SR_OK;
+    if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    ENTER_DEVICE(h);
     uint64_t ds = 0;
     int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
     if (rc) return rc;
+    if ((rc = check_pcm(h, h->s_pcm.p, ds, buf_len))) return rc;
     if ((rc = h->s_vad.reserve(B))) return rc;
     DevBuf<uint64_t> dm;
     if ((rc = dm.reserve((size_t)B * 16))) return rc;
@@ -790,12 +889,15 @@ int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32
     if (!h || !pcm || !start || !end || !mid || !mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
     if (B == 0) return SR_OK;
     if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     // build the per-utterance records the frame kernel consumes (what k_vad would have produced)
     std::vector<sr_vad_rec> recs(B);
     for (uint32_t b = 0; b < B; b++) {
         sr_vad_rec &r = recs[b];
         std::memset(&r, 0, sizeof r);
+        // samples and mid are 16-bit quantities in the reference (u16 VcBuf, mid_val = a mean of u16 samples,
+        // VAD.C:41-47); the frame kernel's 24-bit multiplies rely on |sample - mid| < 2^23
+        if (mid[b] > 0xFFFFu) return fail(SR_ERR_BAD_ARG, "mid exceeds the u16 sample range");
         r.atap.mid_val = mid[b];
         for (int i = 0; i < 2 * SR_MAX_SEG; i++) r.seg[i] = -1;
         r.seg[0] = start[b];
@@ -831,7 +933,7 @@ int sr_train_store(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint3
     const uint32_t slot_rows = (stride_bytes - 4) / (2 * kCoef);
     for (uint32_t i = 0; i < n; i++)
         if (slot[i] >= n_slots) return fail(SR_ERR_BAD_ARG, "slot index outside the store");  // Flash.C:22-26
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     uint64_t ds = 0;
     int rc = stage_pcm(h, pcm, pcm_stride, buf_len, n, &ds);
     if (rc) return rc;
@@ -868,7 +970,7 @@ int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames
     if (B == 0) return SR_OK;
     for (uint32_t b = 0; b < B; b++)
         if (in_frames[b] > h->cfg.max_frames) return fail(SR_ERR_BAD_ARG, "in_frames exceeds max_frames");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
     if ((rc = h->s_mfcc.reserve(msz))) return rc;
@@ -898,7 +1000,7 @@ int sr_get_mdl_batch(sr_engine *h, const int16_t *in1, const uint32_t *n1, uint3
     for (uint32_t p = 0; p < P; p++)
         if (n1[p] > rows1 || n2[p] > rows2 || n1[p] > 0xFFFF || n2[p] > 0xFFFF)
             return fail(SR_ERR_BAD_ARG, "frame count exceeds the rows of its record (or the u16 range)");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     const size_t e1 = (size_t)P * rows1 * kCoef, e2 = (size_t)P * rows2 * kCoef, eo = (size_t)P * mdl_rows * kCoef;
     if ((rc = h->s_mfcc.reserve(e1 + e2 + eo + 16))) return rc;
@@ -927,7 +1029,7 @@ int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_i
     if (!h || !d_mfcc || !d_scores || (!d_in_frames && !d_vad)) return fail(SR_ERR_BAD_ARG, "null argument");
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
     if ((size_t)h->tpl_rows * 48 > 150 * 1024) return fail(SR_ERR_BAD_ARG, "templates too long for the LDS-staged DP kernel");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     DtwArgs a = dtw_args(h, d_mfcc, d_vad, d_in_frames, B, d_scores, nullptr);
     launch_dtw_dp(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -941,7 +1043,7 @@ int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_fra
     if (B == 0) return SR_OK;
     for (uint32_t b = 0; b < B; b++)
         if (in_frames[b] > h->cfg.max_frames) return fail(SR_ERR_BAD_ARG, "in_frames exceeds max_frames");
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
     if ((rc = h->s_mfcc.reserve(msz))) return rc;
@@ -959,7 +1061,7 @@ int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
 {
     if (!h || !in || !out) return fail(SR_ERR_BAD_ARG, "null argument");
     if (n == 0) return SR_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     if ((rc = h->s_u32a.reserve(n))) return rc;
     if ((rc = h->s_u32b.reserve((size_t)3 * n))) return rc;
@@ -974,7 +1076,7 @@ int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n
 {
     if (!h || !in || !out) return fail(SR_ERR_BAD_ARG, "null argument");
     if (n == 0) return SR_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     if ((rc = h->s_u32a.reserve((size_t)n * kNfft))) return rc;
     if ((rc = h->s_u32b.reserve((size_t)n * kNfft))) return rc;
@@ -991,7 +1093,7 @@ int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n
 namespace sr {
 int engine_fft_mag(sr_engine *h, const int16_t *frame, uint32_t len, uint32_t *mag, uint32_t *raw_hi)
 {
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     if ((rc = h->s_mfcc.reserve(len > 0 ? len : 1))) return rc;
     if ((rc = h->s_u32a.reserve(kBins))) return rc;
@@ -1006,7 +1108,7 @@ int engine_fft_mag(sr_engine *h, const int16_t *frame, uint32_t len, uint32_t *m
 
 int engine_get_dis(sr_engine *h, const int16_t *a, const int16_t *b, uint32_t *out)
 {
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     if ((rc = h->s_mfcc.reserve(2 * kCoef))) return rc;
     if ((rc = h->s_u32a.reserve(1))) return rc;
@@ -1020,7 +1122,7 @@ int engine_get_dis(sr_engine *h, const int16_t *a, const int16_t *b, uint32_t *o
 
 int engine_dtw_limit(sr_engine *h, uint16_t x, uint16_t y, int X1, int X2, int in_n, int mdl_n, uint8_t *out)
 {
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     int rc;
     if ((rc = h->s_u32a.reserve(2))) return rc;
     const uint16_t xy[2] = {x, y};
@@ -1033,7 +1135,7 @@ int engine_dtw_limit(sr_engine *h, uint16_t x, uint16_t y, int X1, int X2, int i
 
 int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, const sr_atap *atap, sr_vad_rec *rec)
 {
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     uint64_t ds = 0;
     int rc = stage_pcm(h, pcm, buf_len, buf_len, 1, &ds);
     if (rc) return rc;
@@ -1051,7 +1153,7 @@ int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, co
 // interest; only the atap part of the record is used)
 int engine_noise_atap(sr_engine *h, const uint16_t *noise, uint32_t n_len, sr_atap *out)
 {
-    HIP_TRY(hipSetDevice(h->device));
+    ENTER_DEVICE(h);
     uint64_t ds = 0;
     int rc = stage_pcm(h, noise, n_len, n_len, 1, &ds);
     if (rc) return rc;

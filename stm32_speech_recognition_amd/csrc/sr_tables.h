@@ -36,7 +36,7 @@ struct HostTables {
     //   tw_a = (Kc, Ks)   -> re' = Yr*Kc + Yi*Ks
     //   tw_b = (-Ks, Kc)  -> im' = Yi*Kc - Yr*Ks
     std::vector<uint32_t> tw_a, tw_b;  // [1020]
-    std::vector<int16_t> tw_kr, tw_ki; // raw (Kr', Ki) as in the .s table, for tests
+    std::vector<int16_t> tw_kr, tw_ki; // raw (Kr', Ki) columns as in the .s table (exported by sr_build_tables, diffed by tests)
     // log_thr[m] = smallest n with (u32)(log((double)n)*100) >= m, m = 0..2218; [2219] = sentinel.
     std::vector<uint32_t> log_thr;
     // EXTENSION only: Q14 (cos, sin)(2*pi*k/512), k < 256, packed like the butterfly coefficients

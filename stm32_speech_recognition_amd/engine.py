@@ -63,6 +63,30 @@ def _vp(x):
     return C.c_void_p(x.data_ptr())
 
 
+class _Tables(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("hamm", "tri_cen", "tri_even", "tri_odd", "dct", "tw_kr", "tw_ki", "log_thr")]
+
+
+def build_tables(**kw):
+    """Host-only sr_build_tables(): the constant tables sr_create generates for a configuration (no GPU touched).
+    Keywords override sr_default_config fields (fs=16000, nfft=512, n_mel=40 for the extension front end)."""
+    L = load_library()
+    cfg = Config()
+    L.sr_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    frame_len, nb = cfg.fs // 1000 * cfg.frame_time_ms, cfg.nfft // 2
+    out = dict(hamm=np.zeros(frame_len, np.uint16), tri_cen=np.zeros(cfg.n_mel, np.uint16),
+               tri_even=np.zeros(nb, np.uint16), tri_odd=np.zeros(nb, np.uint16),
+               dct=np.zeros(cfg.n_coef * cfg.n_mel, np.int8), tw_kr=np.zeros(1020, np.int16),
+               tw_ki=np.zeros(1020, np.int16), log_thr=np.zeros(2220, np.uint32))
+    t = _Tables(**{k: v.ctypes.data_as(C.c_void_p) for k, v in out.items()})
+    rc = L.sr_build_tables(C.byref(cfg), C.byref(t))
+    if rc != 0:
+        raise SrError(f"sr_build_tables error {rc}: {L.sr_last_error().decode()}")
+    return out
+
+
 class Engine:
     """One sr_engine handle.  Defaults are the firmware's constants except where overridden."""
 

@@ -6,6 +6,8 @@ module.  The product package never does.
   Oracle  -- tier (ii): oracle/liboracle.so, own parametrised restatement
   RefLib  -- tier (i):  oracle/_ref/libsr_ref.so, the reference's own VAD.C /
              MFCC.C / DTW.C compiled verbatim (+ C transcription of the asm FFT)
+  RefLib320 -- the same objects built with vv_tim_max = 3210 ms (320 frames instead of
+             119; oracle/Makefile), so the reference's own code runs the benchmark shape
 """
 import ctypes as C
 import os
@@ -17,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_PATH = os.path.join(ORACLE_DIR, "_ref", "libsr_ref.so")
+REF320_PATH = os.path.join(ORACLE_DIR, "_ref", "libsr_ref320.so")   # same objects, vv_tim_max patched to 320 frames
 
 DIS_ERR = 0xFFFFFFFF
 ST_OK, ST_VAD_FAIL, ST_MFCC_FAIL, ST_SEG_OOB = 0, 1, 2, 3
@@ -27,7 +30,7 @@ def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("sr_oracle.c", "sr_oracle.h", "q15_fft.c", "ref_glue.c", "Makefile")]
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
-    if os.path.isdir("/root/reference/Src/Speech_Recog") and not os.path.exists(REF_PATH):
+    if os.path.isdir("/root/reference/Src/Speech_Recog") and not (os.path.exists(REF_PATH) and os.path.exists(REF320_PATH)):
         stale = True
     if stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "all"], stdout=subprocess.DEVNULL)
@@ -206,19 +209,21 @@ Oracle.dtw_dp = _oracle_dtw_dp
 class RefLib:
     """Tier (i): the reference's own objects.  Non-reentrant (file-scope statics): single thread only."""
     FTR_BYTES = 2860  # sizeof(v_ftr_tag) at vv_frm_max = 119 (MFCC.H:18-25)
+    FRM_MAX = 119
+    PATH = REF_PATH
 
-    @staticmethod
-    def available():
+    @classmethod
+    def available(cls):
         build()
-        return os.path.exists(REF_PATH)
+        return os.path.exists(cls.PATH)
 
     def __init__(self):
         build()
-        self.L = C.CDLL(REF_PATH)
+        self.L = C.CDLL(self.PATH)
         self.L.dtw.restype = C.c_uint32
         self.L.get_dis.restype = C.c_uint32
         self.L.dtw_limit.restype = C.c_uint8
-        assert self.L.sr_ref_sizeof_ftr() == self.FTR_BYTES
+        assert self.L.sr_ref_sizeof_ftr() == self.FTR_BYTES and self.L.sr_ref_vv_frm_max() == self.FRM_MAX
 
     def vad(self, pcm, noise_len=2400):
         """pcm: uint16 [S]; returns (Atap, seg[6])."""
@@ -242,14 +247,14 @@ class RefLib:
         self.L.cr4_fft_1024_stm32(_p(out), _p(words), C.c_uint16(1024))
         return out
 
-    @staticmethod
-    def make_ftr(mfcc, n, save_sign=12345):
+    @classmethod
+    def make_ftr(cls, mfcc, n, save_sign=12345):
         """Pack [n,12] int16 into a v_ftr_tag image (MFCC.H:18-25)."""
-        ftr = np.zeros(RefLib.FTR_BYTES, dtype=np.uint8)
+        ftr = np.zeros(cls.FTR_BYTES, dtype=np.uint8)
         ftr.view(np.uint16)[0] = save_sign
         ftr.view(np.uint16)[1] = n
-        m = np.ascontiguousarray(mfcc, dtype=np.int16).reshape(-1)
-        ftr.view(np.int16)[2:2 + len(m)] = m[:119 * 12]
+        m = np.ascontiguousarray(mfcc, dtype=np.int16).reshape(-1)[:cls.FRM_MAX * 12]
+        ftr.view(np.int16)[2:2 + len(m)] = m
         return ftr
 
     def dtw(self, ftr_in, ftr_mdl):
@@ -277,3 +282,12 @@ class RefLib:
                                          C.byref(best), C.byref(dis), _p(scores))
         n = int(ftr.view(np.uint16)[1])
         return st, best.value, dis.value, scores, ftr.view(np.int16)[2:2 + n * 12].reshape(n, 12).copy(), n
+
+
+class RefLib320(RefLib):
+    """Tier (i) at vv_frm_max = 320: the reference's VAD.C / MFCC.C / DTW.C compiled from where they lie with one
+    compile-time constant changed (vv_tim_max 1200 -> 3210 ms, MFCC.H:15, through a sed-patched temporary copy of that
+    header in the git-ignored build directory; see oracle/Makefile)."""
+    FTR_BYTES = 4 + 320 * 12 * 2
+    FRM_MAX = 320
+    PATH = REF320_PATH
