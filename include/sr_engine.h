@@ -257,6 +257,8 @@ void MFCC_Comp(valid_tag *valid, v_ftr_tag *v_ftr, atap_tag *atap_arg);
 int sr_compat_set_templates(const void *store, uint32_t n_slots, uint32_t stride_bytes);
 int sr_compat_set_labels(const uint8_t *labels, uint32_t n_labels, uint32_t label_stride, uint32_t ftr_per_comm);
 sr_engine *sr_compat_engine(void);
+/* diagnostics: out[0] = uploads of dtw()'s model store so far, out[1] = DTW launches, out[2] = models cached */
+void sr_compat_dtw_stats(uint32_t out[3]);
 
 #ifdef __cplusplus
 }

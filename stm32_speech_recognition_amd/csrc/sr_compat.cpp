@@ -69,6 +69,48 @@ std::vector<uint8_t> g_labels(&kDefaultLabels[0][0], &kDefaultLabels[0][0] + siz
 uint32_t g_n_labels = 18, g_label_stride = 3, g_ftr_per_comm = 4;  // Flash.H:15
 uint8_t g_empty_label[1] = {0};
 
+// dtw(): models seen so far, addressed by content (see dtw() below)
+constexpr uint32_t kRecWords = SR_VV_FRM_MAX * 12;  // s16 per v_ftr_tag record, MFCC.H:23
+constexpr size_t kMaxCachedModels = 128;            // comm_num * ftr_per_comm = 80 in the firmware (Flash.H:15-17)
+struct ModelStore {
+    std::vector<int16_t> rows;     // [n][kRecWords]
+    std::vector<uint32_t> frames;  // [n]
+    std::vector<uint64_t> hash;    // [n]
+    bool dirty = false;            // rows changed since the last upload
+    uint64_t gen = 0;              // bumped whenever the store changes
+    // scores of the last input record against every cached model
+    std::vector<int16_t> in_rows;
+    uint32_t in_frames = 0;
+    uint64_t memo_gen = ~0ull;
+    std::vector<uint32_t> scores;
+    uint32_t uploads = 0, launches = 0;
+
+    static uint64_t fnv(const int16_t *p, uint32_t frm)
+    {
+        uint64_t h = 1469598103934665603ull ^ frm;
+        const uint8_t *b = (const uint8_t *)p;
+        for (size_t i = 0; i < kRecWords * sizeof(int16_t); i++) h = (h ^ b[i]) * 1099511628211ull;
+        return h;
+    }
+    size_t find_or_add(const int16_t *p, uint32_t frm)
+    {
+        const uint64_t hv = fnv(p, frm);
+        for (size_t i = 0; i < frames.size(); i++)
+            if (hash[i] == hv && frames[i] == frm && std::memcmp(&rows[i * kRecWords], p, kRecWords * sizeof(int16_t)) == 0) return i;
+        if (frames.size() == kMaxCachedModels) {
+            rows.clear();
+            frames.clear();
+            hash.clear();
+        }
+        rows.insert(rows.end(), p, p + kRecWords);
+        frames.push_back(frm);
+        hash.push_back(hv);
+        dirty = true;
+        gen++;
+        return frames.size() - 1;
+    }
+} g_models;
+
 }  // namespace
 
 extern "C" {
@@ -184,11 +226,36 @@ uint32_t dtw(v_ftr_tag *ftr_in, v_ftr_tag *frt_mdl)
         std::fprintf(stderr, "dtw: frm_num outside the v_ftr_tag capacity\n");
         std::abort();
     }
-    // model -> 1-slot dense store (all 119 rows, so rows past frm_num read the caller's data as in DTW.C:152-154)
-    if (sr_set_templates_dense(h, frt_mdl->mfcc_dat, &mf, nullptr, 1, SR_VV_FRM_MAX * 12) != SR_OK) die("dtw");
-    uint32_t score = 0;
-    if (sr_dtw_batch(h, ftr_in->mfcc_dat, &inf, 1, &score, nullptr) != SR_OK) die("dtw");
-    return score;
+    // The firmware calls dtw() once per flash slot and utterance (main.c:279-291).  Models are kept in a small
+    // content-addressed store on the device (all 119 rows of a record: rows past frm_num are read as in DTW.C:152-154),
+    // so a slot is uploaded the first time it is seen, not on every call; and one launch scores an input record against
+    // every cached model, so the other 79 calls of the slot scan are look-ups.  Hits are confirmed by comparing the
+    // full records, never by the hash alone.
+    const size_t slot = g_models.find_or_add(frt_mdl->mfcc_dat, mf);
+    if (g_models.dirty) {
+        const uint32_t Kc = (uint32_t)g_models.frames.size();
+        if (sr_set_templates_dense(h, g_models.rows.data(), g_models.frames.data(), nullptr, Kc, kRecWords) != SR_OK) die("dtw");
+        g_models.dirty = false;
+        g_models.uploads++;
+    }
+    if (!(g_models.memo_gen == g_models.gen && g_models.in_frames == inf &&
+          std::memcmp(g_models.in_rows.data(), ftr_in->mfcc_dat, kRecWords * sizeof(int16_t)) == 0)) {
+        g_models.scores.assign(g_models.frames.size(), 0u);
+        if (sr_dtw_batch(h, ftr_in->mfcc_dat, &inf, 1, g_models.scores.data(), nullptr) != SR_OK) die("dtw");
+        g_models.in_rows.assign(ftr_in->mfcc_dat, ftr_in->mfcc_dat + kRecWords);
+        g_models.in_frames = inf;
+        g_models.memo_gen = g_models.gen;
+        g_models.launches++;
+    }
+    return g_models.scores[slot];
+}
+
+// diagnostics for tests: out[0] = uploads of the dtw() model store, out[1] = DTW launches, out[2] = cached models
+void sr_compat_dtw_stats(uint32_t out[3])
+{
+    out[0] = g_models.uploads;
+    out[1] = g_models.launches;
+    out[2] = (uint32_t)g_models.frames.size();
 }
 
 // DTW.C:217-296.  ftr_mdl->save_sign is left alone, frm_num = step (DTW.C:293).  A merged template longer than

@@ -529,6 +529,49 @@ def test_compat_symbols_match_golden(golden, oracle):
     assert label is None and dis == compat.DIS_ERR  # main.c:261-266
 
 
+def test_compat_dtw_slot_scan_uploads_each_model_once(golden):
+    """The firmware's slot scan (main.c:279-291: one dtw() per flash slot and utterance) through the scalar symbol:
+    a model is uploaded the first time it is seen and one launch scores an input record against every cached model,
+    so after the first scan an utterance costs no upload and one launch, and every score still equals the reference objects'."""
+    import ctypes as C
+    from stm32_speech_recognition_amd import compat
+    L = compat._lib()
+    st = (C.c_uint32 * 3)()
+    L.sr_compat_dtw_stats(st)
+    up0, la0 = st[0], st[1]
+    ln, da, db, dd = golden["dtw_len"], golden["dtw_a"], golden["dtw_b"], golden["dtw_dis"]
+    S, U = 24, 5
+    models = [compat.make_ftr(db[p], int(ln[p, 1])) for p in range(S)]
+    want = {}
+    for rnd in range(2):
+        L.sr_compat_dtw_stats(st)
+        up1, la1 = st[0], st[1]
+        for u in range(U):
+            fin = compat.make_ftr(da[u], int(ln[u, 0]))
+            for p in range(S):
+                d = compat.dtw(fin, models[p])
+                if u == p:
+                    assert d == dd[p]                   # the pairs the reference objects scored for the fixture
+                assert want.setdefault((u, p), d) == d
+        L.sr_compat_dtw_stats(st)
+        if rnd == 0:                                    # a slot is uploaded when it first passes the length gate (DTW.C:133-137)
+            assert st[0] - up0 <= S
+        else:                                           # every slot is resident: no upload, one launch per utterance
+            assert st[0] == up1 and st[1] - la1 <= U, (st[0] - up1, st[1] - la1)
+    # same answers in another order (a pure function of the two records)
+    for u in (3, 0):
+        fin = compat.make_ftr(da[u], int(ln[u, 0]))
+        for p in (7, 23, 0):
+            assert compat.dtw(fin, models[p]) == want[(u, p)]
+    # a model whose rows past frm_num differ is a different model (DTW.C:152-154 reads them)
+    m2 = compat.make_ftr(db[0], int(ln[0, 1]))
+    np.ctypeslib.as_array(m2.mfcc_dat)[int(ln[0, 1]) * 12:] = 77
+    fin = compat.make_ftr(da[0], int(ln[0, 0]))
+    compat.dtw(fin, m2)
+    L.sr_compat_dtw_stats(st)
+    assert st[2] >= S + 1
+
+
 # ----------------------------------------------------------------------------- SURVEY 8(f) rows
 def test_recognize_segments_matches_golden(eng119, golden):
     """multi-segment recognition against the reference objects' per-segment get_mfcc + dtw"""

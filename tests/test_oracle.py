@@ -511,3 +511,18 @@ def test_store_image_round_trip(oracle, golden):
     for s_, r in zip(slots, rows):
         assert np.array_equal(tm[s_, :len(r)], r)
     assert (tm[1, :119] == -1).all() and tv[1] == 0  # erased slot: 0xFFFF halves, not valid
+
+
+def test_oracle_is_clean_under_asan_ubsan():
+    """the CPU restatement under AddressSanitizer + UndefinedBehaviorSanitizer.  oracle/selftest.c
+    drives every entry point (both front ends, the sentinel edge cases, full-scale records, the threaded batch call);
+    any out-of-bounds access or undefined operation aborts it."""
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    b = subprocess.run(["make", "-C", odir, "asan"], capture_output=True, text=True)
+    if b.returncode != 0 and ("asan" in b.stderr.lower() or "sanitize" in b.stderr.lower()):
+        pytest.skip("toolchain without sanitizer runtimes: " + b.stderr[-200:])
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([os.path.join(odir, "_ref", "oracle_selftest_asan")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "oracle selftest ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
