@@ -191,6 +191,32 @@ int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_i
 /* generic 1024-point Q15 FFT of n independent packed-complex arrays (re = low half, im = high half) */
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
 
+/* ------------------------------------------------------------------ multi-GPU (one process, several MI355X)
+ * Utterances are sharded over the devices (B_per_dev each), templates are replicated, the argmin is local, and the
+ * path's single exchange step is ONE RCCL all-gather of the per-template score matrix over xGMI: after the call every
+ * device holds u32 scores[n_dev*B_per_dev][K] in global utterance order -- what the firmware's slot scan
+ * (main.c:279-291: cur_dis of every slot) produces, for every utterance of the job.  RCCL (librccl.so.1) is bound at
+ * run time; without it sr_multi_create fails with SR_ERR_NO_DEVICE.  Processes that run one rank per GPU (MPI,
+ * torchrun) keep one sr_engine each and use sr_allgather_scores on their own communicator. */
+typedef struct sr_multi sr_multi;
+int sr_multi_create(const sr_config *cfg, const int *devices, uint32_t n_dev, sr_multi **out); /* cfg->device ignored */
+void sr_multi_destroy(sr_multi *m);
+uint32_t sr_multi_num_devices(const sr_multi *m);
+sr_engine *sr_multi_engine(sr_multi *m, uint32_t i); /* the engine of devices[i] */
+int sr_multi_set_templates(sr_multi *m, const void *store, uint32_t n_slots, uint32_t stride_bytes);
+int sr_multi_set_templates_dense(sr_multi *m, const int16_t *mfcc, const uint32_t *frames, const uint8_t *valid,
+                                 uint32_t n_templates, uint32_t tpl_stride);
+/* device-resident shards: d_pcm[i], d_results[i] (B_per_dev records) and d_scores_all[i] (n_dev*B_per_dev*K words) live
+ * on devices[i]; asynchronous on streams[i] (hipStream_t; streams == NULL: internal streams, returns when drained) */
+int sr_multi_recognize_dev(sr_multi *m, const uint16_t *const *d_pcm, uint64_t pcm_stride, uint32_t buf_len,
+                           uint32_t B_per_dev, sr_result *const *d_results, uint32_t *const *d_scores_all,
+                           void *const *streams);
+/* host buffers: shards, uploads, recognises, gathers; results[B], scores[B*K] (optional, read back from devices[0]) */
+int sr_multi_recognize(sr_multi *m, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                       sr_result *results, uint32_t *scores);
+/* the exchange step alone on a caller-owned ncclComm_t: d_all[n_ranks*count] <- all ranks' d_scores[count] */
+int sr_allgather_scores(void *nccl_comm, const uint32_t *d_scores, uint32_t *d_all, uint64_t count, void *stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 2048 utterances each, at most
  * SR_PIPE_MAX_CHUNKS = 12) and runs them on SR_PIPE_STREAMS = 3 (max 4) internal streams forked from / joined to the

@@ -21,6 +21,7 @@ static int fail(int code, const std::string &msg)
     g_err = msg;
     return code;
 }
+int set_error(int code, const std::string &msg) { return fail(code, msg); }  // for the other translation units
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \

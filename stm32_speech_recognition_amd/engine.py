@@ -307,3 +307,70 @@ def results_from_torch(t):
 
 def vad_from_torch(t):
     return t.cpu().numpy().view(np.uint8).reshape(-1, 48).copy().view(VAD_DTYPE).reshape(-1)
+
+
+class MultiEngine:
+    """sr_multi: ONE process driving several MI355X (utterances sharded, templates replicated, one RCCL all-gather of
+    the score matrix).  Mirrors the sr_multi_* section of include/sr_engine.h."""
+
+    def __init__(self, devices, max_frames=119, **kw):
+        self.L = load_library()
+        self.L.sr_multi_num_devices.restype = C.c_uint32
+        cfg = Config()
+        self.L.sr_default_config(C.byref(cfg))
+        cfg.max_frames = max_frames
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        self.cfg, self.max_frames = cfg, max_frames
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        self._check(self.L.sr_multi_create(C.byref(cfg), devs, C.c_uint32(len(devices)), C.byref(h)))
+        self.h, self.devices, self.K = h, list(devices), 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SrError(f"sr_multi error {rc}: {self.L.sr_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sr_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_templates_dense(self, mfcc, frames, valid=None):
+        mfcc = np.ascontiguousarray(mfcc, dtype=np.int16)
+        frames = np.ascontiguousarray(frames, dtype=np.uint32)
+        K = mfcc.shape[0]
+        valid = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
+        self._check(self.L.sr_multi_set_templates_dense(self.h, _vp(mfcc), _vp(frames), _vp(valid), C.c_uint32(K),
+                                                        C.c_uint32(mfcc.shape[1] * mfcc.shape[2])))
+        self.K = K
+
+    def set_templates_store(self, store, stride=4096):
+        store = np.ascontiguousarray(store, dtype=np.uint8)
+        self._check(self.L.sr_multi_set_templates(self.h, _vp(store), C.c_uint32(len(store) // stride), C.c_uint32(stride)))
+        self.K = len(store) // stride
+
+    def recognize(self, pcm):
+        """pcm uint16 [B, S] on the host -> (results [B], gathered scores [B, K])"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        B, S = pcm.shape
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        sc = np.zeros((B, self.K), dtype=np.uint32)
+        self._check(self.L.sr_multi_recognize(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B), _vp(res), _vp(sc)))
+        return res, sc
+
+    def recognize_dev(self, pcm_list, results_list, scores_all_list, buf_len=None):
+        """device-resident shards: torch tensors per device (pcm int16/uint16 [Bp, S], results int32 [Bp, 4],
+        scores_all int32 [n_dev*Bp, K]); synchronous (internal streams)."""
+        n = len(self.devices)
+        Bp, S = pcm_list[0].shape
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._check(self.L.sr_multi_recognize_dev(self.h, arr(pcm_list), C.c_uint64(pcm_list[0].stride(0)),
+                                                  C.c_uint32(S if buf_len is None else buf_len), C.c_uint32(Bp),
+                                                  arr(results_list), arr(scores_all_list), None))

@@ -51,15 +51,17 @@ def test_no_cpu_fallback_without_gpu():
         engine.Engine()
 
 
-def build_c_demo(out_path):
-    """examples/spch_recg_demo.c = the reference's main.c:258-283 call pattern, plain C, linked against the library"""
+def build_c_demo(out_path, src="spch_recg_demo.c"):
+    """examples/spch_recg_demo.c = the reference's main.c:258-283 call pattern, plain C, linked against the library;
+    examples/multi_gpu_demo.c = the multi-GPU surface from plain C"""
     import subprocess
     lib_dir = os.path.join(ROOT, "stm32_speech_recognition_amd")
     subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "spch_recg_demo.c"), "-L" + lib_dir, "-lsr_engine",
+                           os.path.join(ROOT, "examples", src), "-L" + lib_dir, "-lsr_engine",
                            "-Wl,-rpath," + lib_dir, "-o", out_path])
 
 
 def test_c_demo_compiles_and_links_as_plain_c(tmp_path):
     engine.load_library()
     build_c_demo(str(tmp_path / "spch_recg_demo"))
+    build_c_demo(str(tmp_path / "multi_gpu_demo"), "multi_gpu_demo.c")

@@ -3,6 +3,7 @@ committed golden fixtures (which come from the reference's own objects).  Bit-ex
 the whole path is integer except sqrtf / log, which are reproduced exactly.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -572,6 +573,64 @@ def test_compat_dtw_slot_scan_uploads_each_model_once(golden):
     assert st[2] >= S + 1
 
 
+# ----------------------------------------------------------------------------- multi-GPU surface of the C ABI
+def _multi_case(devices, golden):
+    """sr_multi_* on `devices`: sharded recognition + RCCL all-gather == the single-engine answer, host and device API"""
+    from stm32_speech_recognition_amd.engine import Engine, MultiEngine, results_from_torch
+    pcm = np.concatenate([golden["pcm"], golden["pcm"][::-1][:5]])        # 37 captures: uneven shards on 2+ devices
+    e1 = Engine(device=devices[0])
+    e1.set_templates_store(golden["store"])
+    want = e1.recognize(pcm, want_mfcc=False, want_vad=False)
+    me = MultiEngine(devices)
+    me.set_templates_store(golden["store"])
+    res, sc = me.recognize(pcm)
+    for f in ("best_tpl", "min_dis", "frm_num", "status"):
+        assert np.array_equal(res[f], want["results"][f]), f
+    assert np.array_equal(sc, want["scores"])
+    # device-resident shards, equal size: every device ends up with the whole score matrix
+    n, Bp, K = len(devices), 12, me.K
+    pl, rl, al = [], [], []
+    for i, d in enumerate(devices):
+        dev = torch.device("cuda", d)
+        pl.append(torch.from_numpy(pcm[i * Bp:(i + 1) * Bp].view(np.int16)).to(dev))
+        rl.append(torch.zeros(Bp, 4, dtype=torch.int32, device=dev))
+        al.append(torch.full((n * Bp, K), -1, dtype=torch.int32, device=dev))
+    me.recognize_dev(pl, rl, al)
+    for i in range(n):
+        assert np.array_equal(al[i].cpu().numpy().view(np.uint32), want["scores"][:n * Bp]), i
+        r = results_from_torch(rl[i])
+        assert np.array_equal(r["best_tpl"], want["results"]["best_tpl"][i * Bp:(i + 1) * Bp])
+    me.close()
+    e1.close()
+
+
+def test_multi_gpu_c_abi_single_device(golden):
+    _multi_case([0], golden)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X in one node")
+def test_multi_gpu_c_abi_two_devices(golden):
+    _multi_case([0, 1], golden)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X in one node")
+def test_bench_two_ranks_over_rccl():
+    """bench.py exactly as the driver launches it at N = 2: one rank per GPU, backend nccl (= RCCL over xGMI)"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SR_BENCH_BACKEND", None)
+    env.pop("SR_BENCH_DEVICE", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]
+
+
 # ----------------------------------------------------------------------------- SURVEY 8(f) rows
 def test_recognize_segments_matches_golden(eng119, golden):
     """multi-segment recognition against the reference objects' per-segment get_mfcc + dtw"""
@@ -808,6 +867,23 @@ def test_log_and_sqrt_device_functions_swept_directly(eng119):
     orc.L.sr_oracle_math_diag(x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), C.c_uint32(len(x)))
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (x[bad[:5] // 3], bad[:5] % 3, got[bad[:5]], want[bad[:5]])
+
+
+def test_c_multi_gpu_demo(golden, tmp_path):
+    """examples/multi_gpu_demo.c: sr_multi_* from a plain-C process on every GPU of the box (1 on the test box)"""
+    import subprocess
+    from test_abi_symbols import build_c_demo
+    exe = str(tmp_path / "multi_gpu_demo")
+    build_c_demo(exe, "multi_gpu_demo.c")
+    golden["store"].tofile(str(tmp_path / "store.bin"))
+    nb = len(golden["recg_best"])
+    golden["pcm"][:nb].tofile(str(tmp_path / "caps.bin"))
+    n = torch.cuda.device_count()
+    out = subprocess.run([exe, str(tmp_path / "store.bin"), str(tmp_path / "caps.bin"), str(n)], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and f"on {n} device(s), gathered scores identical" in out.stdout, out.stdout + out.stderr
+    for b in range(nb):
+        assert f"capture {b}: slot {golden['recg_best'][b]} dis {golden['recg_dis'][b]} " in out.stdout
 
 
 def test_c_demo_reference_call_pattern(golden, tmp_path):
