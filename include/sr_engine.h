@@ -188,6 +188,14 @@ int sr_get_mdl_batch(sr_engine *h, const int16_t *in1, const uint32_t *n1, uint3
 int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores);
 int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_in_frames, const sr_vad_rec *d_vad,
                         uint32_t B, uint32_t *d_scores, void *stream);
+/* EXTENSION, NO REFERENCE COUNTERPART (the thesis that accompanies the reference, p.32, lists difference cepstra as
+ * future work; the firmware computes none): delta MFCC by the standard two-frame regression over the s16 rows,
+ *   delta[t][c] = ((m[t+1][c] - m[t-1][c]) + 2*(m[t+2][c] - m[t-2][c])) / 10,
+ * row indices clamped to [0, frames-1], s32 arithmetic, division truncating toward zero; rows >= frames are zero.
+ * mfcc / delta: [B][max_frames][n_coef].  Never used by the recognition path or the reference-compatible symbols. */
+int sr_delta_mfcc_batch(sr_engine *h, const int16_t *mfcc, const uint32_t *frames, uint32_t B, int16_t *delta);
+int sr_delta_mfcc_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_vad /* or */, const uint32_t *d_frames,
+                            uint32_t B, int16_t *d_delta, void *stream);
 /* generic 1024-point Q15 FFT of n independent packed-complex arrays (re = low half, im = high half) */
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
 

@@ -686,3 +686,24 @@ void sr_oracle_recognize_batch(const sr_oracle *o, const uint16_t *pcm, uint64_t
     if (n_threads > 1)
         for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
 }
+
+/* ---- EXTENSION, no reference counterpart: first-order difference cepstra ("delta MFCC") ---------------------------
+ * The thesis that accompanies the reference (p.32) names difference cepstra as future work; the firmware has none.
+ * Definition used by this repository (the product kernel k_delta_mfcc mirrors it):
+ *   the standard two-frame regression over the s16 MFCC rows of one record,
+ *     d[t][c] = ( (m[t+1][c] - m[t-1][c]) + 2*(m[t+2][c] - m[t-2][c]) ) / 10
+ *   with row indices clamped to [0, n-1] (edge replication), all arithmetic in s32 and the division truncating toward
+ *   zero like every division of MFCC.C (C99); |numerator| <= 6*65535, so the quotient always fits s16.
+ * out[n][nc]; rows are independent of anything past row n-1. */
+void sr_oracle_delta_mfcc(const int16_t *m, uint32_t n, uint32_t nc, int16_t *out)
+{
+    for (uint32_t t = 0; t < n; t++) {
+        const uint32_t p1 = t + 1 < n ? t + 1 : n - 1, p2 = t + 2 < n ? t + 2 : n - 1;
+        const uint32_t m1 = t >= 1 ? t - 1 : 0, m2 = t >= 2 ? t - 2 : 0;
+        for (uint32_t c = 0; c < nc; c++) {
+            const int32_t num = ((int32_t)m[p1 * nc + c] - (int32_t)m[m1 * nc + c]) +
+                                2 * ((int32_t)m[p2 * nc + c] - (int32_t)m[m2 * nc + c]);
+            out[t * nc + c] = (int16_t)(num / 10);
+        }
+    }
+}

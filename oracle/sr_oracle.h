@@ -95,6 +95,9 @@ void sr_oracle_math_diag(const uint32_t *in, uint32_t *out, uint32_t n);
 uint32_t sr_oracle_dtw_dp(const int16_t *in, uint32_t in_frames, const int16_t *mdl, uint32_t mdl_frames,
                           uint32_t n_coef);
 
+/* EXTENSION (no reference counterpart): two-frame regression delta cepstra of one record, see sr_oracle.c */
+void sr_oracle_delta_mfcc(const int16_t *m, uint32_t n, uint32_t nc, int16_t *out);
+
 /*
  * Template store in the batched layout: tpl_mfcc[k] starts at k*tpl_stride int16s,
  * frame-major; tpl_frames[k] = frm_num; tpl_valid[k] != 0 <=> save_sign == 12345.

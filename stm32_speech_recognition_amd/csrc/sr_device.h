@@ -109,6 +109,9 @@ void launch_fft_q15(const uint32_t *in, uint32_t *out, uint32_t n, const DevTabl
 // frames: [n][160] int16; mag: [n][512]; also writes raw FFT words of bins 512..1023 to raw_hi if non-null
 void launch_fft_mag(const int16_t *frames, uint32_t len, uint32_t *mag, uint32_t *raw_hi, uint32_t n,
                     const DevTables &t, hipStream_t s);
+// EXTENSION: delta cepstra of B records (frame counts from vad[] or, when non-null, frames[])
+void launch_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames, uint32_t B, uint32_t max_frames,
+                       int16_t *delta, hipStream_t s);
 // diagnostics: log / sqrt device functions swept directly (see k_math_diag)
 void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
 // get_dis (DTW.C:45-62) for n frame pairs

@@ -1057,6 +1057,34 @@ int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_fra
     return SR_OK;
 }
 
+// EXTENSION (no reference counterpart): delta cepstra, see k_delta_mfcc
+int sr_delta_mfcc_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_vad, const uint32_t *d_frames,
+                            uint32_t B, int16_t *d_delta, void *stream)
+{
+    if (!h || !d_mfcc || !d_delta || (!d_vad && !d_frames)) return fail(SR_ERR_BAD_ARG, "null argument");
+    if ((uint64_t)B * h->cfg.max_frames * kCoef > 0xFFFFFFFFull * 256) return fail(SR_ERR_BAD_ARG, "batch too large");
+    ENTER_DEVICE(h);
+    launch_delta_mfcc(d_mfcc, d_vad, d_frames, B, h->cfg.max_frames, d_delta, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_delta_mfcc_batch(sr_engine *h, const int16_t *mfcc, const uint32_t *frames, uint32_t B, int16_t *delta)
+{
+    if (!h || !mfcc || !frames || !delta) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (B == 0) return SR_OK;
+    ENTER_DEVICE(h);
+    int rc;
+    const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
+    if ((rc = h->s_mfcc.reserve(2 * msz))) return rc;
+    if ((rc = h->s_u32a.reserve(B))) return rc;
+    HIP_TRY(hipMemcpy(h->s_mfcc.p, mfcc, msz * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->s_u32a.p, frames, (size_t)B * 4, hipMemcpyHostToDevice));
+    if ((rc = sr_delta_mfcc_batch_dev(h, h->s_mfcc.p, nullptr, h->s_u32a.p, B, h->s_mfcc.p + msz, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(delta, h->s_mfcc.p + msz, msz * 2, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 // diagnostics: out[3*i + {0,1,2}] = (u32)(log(x)*100), (u32)sqrtf(x), (u32)(sqrtf((s32)x)*10) as the kernels compute them
 int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
 {

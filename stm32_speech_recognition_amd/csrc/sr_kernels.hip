@@ -1854,6 +1854,39 @@ void launch_dtw_dp(const DtwArgs &a, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_delta_mfcc: EXTENSION, no reference counterpart (the accompanying thesis, p.32, lists difference cepstra as future
+// work).  Two-frame regression over the s16 MFCC rows of a record, d[t] = ((m[t+1]-m[t-1]) + 2(m[t+2]-m[t-2])) / 10 with
+// rows clamped to [0, n-1], s32 arithmetic, division truncating toward zero (as every division of MFCC.C); rows >= n
+// are zero.  Defined in oracle/sr_oracle.c (sr_oracle_delta_mfcc); pure streaming: one thread per output element.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames,
+                                                    uint32_t B, uint32_t max_frames, int16_t *delta)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per = max_frames * kCoef;
+    if (i >= (uint64_t)B * per) return;
+    const uint32_t b = (uint32_t)(i / per), r = (uint32_t)(i - (uint64_t)b * per), t = r / kCoef, c = r - t * kCoef;
+    uint32_t n = frames ? frames[b] : ((vad[b].status == SR_ST_OK) ? vad[b].frm_num : 0u);
+    if (n > max_frames) n = max_frames;
+    int16_t out = 0;
+    if (t < n) {
+        const int16_t *m = mfcc + (uint64_t)b * per + c;
+        const uint32_t p1 = t + 1 < n ? t + 1 : n - 1, p2 = t + 2 < n ? t + 2 : n - 1;
+        const uint32_t m1 = t >= 1 ? t - 1 : 0, m2 = t >= 2 ? t - 2 : 0;
+        const int num = ((int)m[p1 * kCoef] - (int)m[m1 * kCoef]) + 2 * ((int)m[p2 * kCoef] - (int)m[m2 * kCoef]);
+        out = (int16_t)(num / 10);
+    }
+    delta[i] = out;
+}
+void launch_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames, uint32_t B, uint32_t max_frames,
+                       int16_t *delta, hipStream_t s)
+{
+    const uint64_t n = (uint64_t)B * max_frames * kCoef;
+    if (!n) return;
+    hipLaunchKernelGGL(k_delta_mfcc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, mfcc, vad, frames, B, max_frames, delta);
+}
+
+// ------------------------------------------------------------------------------------------------
 // diagnostics: the three non-integer device functions on their own, so tests can sweep them directly
 //   out[3i+0] = (u32)(log((double)x)*100)                       MFCC.C:168   (step-function evaluation)
 //   out[3i+1] = (u32)sqrtf((float)x)                            DTW.C:59     (v_sqrt_f32 + fused-residual correction)

@@ -239,6 +239,15 @@ class Engine:
                                             _vp(frames), _vp(dis)))
         return mdl, frames, dis
 
+    def delta_mfcc(self, mfcc, frames):
+        """EXTENSION (no reference counterpart): two-frame regression delta cepstra of B records [B, max_frames, 12]."""
+        mfcc = np.ascontiguousarray(mfcc, dtype=np.int16)
+        frames = np.ascontiguousarray(frames, dtype=np.uint32)
+        assert mfcc.shape[1:] == (self.max_frames, N_COEF)
+        out = np.zeros_like(mfcc)
+        self._check(self.L.sr_delta_mfcc_batch(self.h, _vp(mfcc), _vp(frames), C.c_uint32(len(frames)), _vp(out)))
+        return out
+
     def fft_q15(self, words):
         """cr4_fft_1024_stm32 on uint32 [n, 1024] packed complex arrays."""
         words = np.ascontiguousarray(words, dtype=np.uint32)

@@ -2,9 +2,10 @@
 
 The firmware captures 12-bit right-aligned ADC codes around mid-scale (Src/BSP/ADC.C, ADC.H:7-11); the
 reference's own recordings (Matlab/语音样本/*.wav) are 8 kHz, 8- or 16-bit PCM.  Conversion keeps the top 12
-bits and re-biases to 2048.  Host-side plumbing only; no resampling (the sample rate must already match the
-engine's front end: 8 kHz reference, 16 kHz extension)."""
+bits and re-biases to 2048.  Host-side plumbing only.  Recordings at another rate are brought to the front end's rate
+(8 kHz reference, 16 kHz extension) by a polyphase FIR resampler before the 12-bit conversion."""
 import wave
+from math import gcd
 
 import numpy as np
 
@@ -20,16 +21,39 @@ def pcm_to_adc(samples, sample_width):
     return np.clip(x, 0, 4095).astype(np.uint16)
 
 
-def wav_to_adc(path, expect_rate=None):
-    """Read a mono/stereo PCM WAV (first channel) and return uint16 ADC-like codes."""
+def resample_pcm(x, rate_in, rate_out, taps_per_phase=24):
+    """Polyphase FIR rate conversion of signed samples (float64 in, float64 out): zero-stuff by L, windowed-sinc
+    low-pass at min(rate_in, rate_out) / 2 (Kaiser, beta 8.6), keep every M-th sample; L / M = rate_out / rate_in
+    reduced.  Written with numpy only; the filter is linear-phase and its delay is removed."""
+    if rate_in == rate_out:
+        return np.asarray(x, dtype=np.float64)
+    g = gcd(int(rate_in), int(rate_out))
+    L, M = int(rate_out) // g, int(rate_in) // g
+    half = taps_per_phase * max(L, M)
+    n = np.arange(-half, half + 1)
+    fc = 0.5 / max(L, M)                                        # cycles per sample at the rate rate_in * L
+    h = 2 * fc * np.sinc(2 * fc * n) * np.kaiser(len(n), 8.6) * L
+    up = np.zeros(len(x) * L, dtype=np.float64)
+    up[::L] = np.asarray(x, dtype=np.float64)
+    y = np.convolve(up, h)[half:half + len(up)]
+    return y[::M]
+
+
+def wav_to_adc(path, expect_rate=None, resample=False):
+    """Read a mono/stereo PCM WAV (first channel) and return uint16 ADC-like codes.  A rate other than expect_rate is
+    an error unless resample=True, in which case the signal is converted with resample_pcm()."""
     with wave.open(path, "rb") as w:
         sw, ch, rate, n = w.getsampwidth(), w.getnchannels(), w.getframerate(), w.getnframes()
         raw = w.readframes(n)
-    if expect_rate is not None and rate != expect_rate:
-        raise ValueError(f"{path}: sample rate {rate} Hz, engine front end expects {expect_rate} Hz")
     data = np.frombuffer(raw, dtype=np.int16 if sw == 2 else np.uint8)
     if ch > 1:
         data = data[::ch]
+    if expect_rate is not None and rate != expect_rate:
+        if not resample:
+            raise ValueError(f"{path}: sample rate {rate} Hz, engine front end expects {expect_rate} Hz")
+        x = data.astype(np.float64) if sw == 2 else (data.astype(np.float64) - 128.0) * 256.0
+        y = np.clip(np.round(resample_pcm(x, rate, expect_rate)), -32768, 32767).astype(np.int16)
+        return pcm_to_adc(y, 2)
     return pcm_to_adc(data, sw)
 
 

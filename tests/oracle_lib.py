@@ -206,6 +206,17 @@ def _oracle_dtw_dp(self, a, na, b, nb):
 Oracle.dtw_dp = _oracle_dtw_dp
 
 
+def _oracle_delta_mfcc(self, m, n):
+    """EXTENSION (own definition, sr_oracle.c): delta cepstra of one record [>= n, n_coef] -> [n, n_coef]."""
+    m = np.ascontiguousarray(m, dtype=np.int16)
+    out = np.zeros((n, self.n_coef), dtype=np.int16)
+    self.L.sr_oracle_delta_mfcc(_p(m), C.c_uint32(n), C.c_uint32(self.n_coef), _p(out))
+    return out
+
+
+Oracle.delta_mfcc = _oracle_delta_mfcc
+
+
 class RefLib:
     """Tier (i): the reference's own objects.  Non-reentrant (file-scope statics): single thread only."""
     FTR_BYTES = 2860  # sizeof(v_ftr_tag) at vv_frm_max = 119 (MFCC.H:18-25)

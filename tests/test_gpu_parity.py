@@ -573,6 +573,27 @@ def test_compat_dtw_slot_scan_uploads_each_model_once(golden):
     assert st[2] >= S + 1
 
 
+def test_delta_mfcc_extension_matches_its_oracle(eng119, oracle, golden):
+    """EXTENSION (no reference counterpart): k_delta_mfcc == sr_oracle_delta_mfcc, rows >= frames zero"""
+    rng = np.random.default_rng(8)
+    B = 40
+    mf = np.zeros((B, 119, 12), np.int16)
+    fr = np.zeros(B, np.uint32)
+    for b in range(B):
+        if b < 12 and golden["frm_num"][b] > 0:
+            fr[b] = golden["frm_num"][b]
+            mf[b] = golden["mfcc"][b]
+        else:
+            fr[b] = [0, 1, 2, 3, 4, 5, 119][b % 7] if b < 30 else rng.integers(1, 120)
+            mf[b, :fr[b]] = rng.integers(-32768, 32768, (fr[b], 12))
+    mf[:, 100:] = np.where(np.arange(119)[None, 100:, None] >= fr[:, None, None], 77, mf[:, 100:])  # junk past the record
+    got = eng119.delta_mfcc(mf, fr)
+    for b in range(B):
+        n = int(fr[b])
+        assert np.array_equal(got[b, :n], oracle.delta_mfcc(mf[b], n)), b
+        assert not got[b, n:].any()
+
+
 # ----------------------------------------------------------------------------- multi-GPU surface of the C ABI
 def _multi_case(devices, golden):
     """sr_multi_* on `devices`: sharded recognition + RCCL all-gather == the single-engine answer, host and device API"""

@@ -526,3 +526,18 @@ def test_oracle_is_clean_under_asan_ubsan():
     r = subprocess.run([os.path.join(odir, "_ref", "oracle_selftest_asan")], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and "oracle selftest ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_delta_mfcc_definition(oracle, golden):
+    """EXTENSION, no reference counterpart: the oracle's delta cepstra against an independent numpy statement of the
+    definition (two-frame regression, clamped rows, truncation toward zero) on real MFCC records and full-scale ones."""
+    rng = np.random.default_rng(5)
+    recs = [(int(golden["frm_num"][b]), golden["mfcc"][b]) for b in range(6) if golden["frm_num"][b] > 0]
+    recs += [(n, rng.integers(-32768, 32768, (n, 12)).astype(np.int16)) for n in (1, 2, 3, 4, 5, 40)]
+    for n, m in recs:
+        m = np.ascontiguousarray(m[:n]).astype(np.int64)
+        idx = np.arange(n)
+        c = lambda k: m[np.clip(idx + k, 0, n - 1)]
+        num = (c(1) - c(-1)) + 2 * (c(2) - c(-2))
+        want = (np.sign(num) * (np.abs(num) // 10)).astype(np.int16)
+        assert np.array_equal(oracle.delta_mfcc(m.astype(np.int16), n), want), n

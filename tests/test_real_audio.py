@@ -79,3 +79,26 @@ def test_real_speech_tier2_equals_tier1():
             d1 = r.dtw(feats[i][2], feats[j][2])
             d2 = o.dtw(np.concatenate([feats[i][1], pad]), feats[i][0], np.concatenate([feats[j][1], pad]), feats[j][0])
             assert d1 == d2
+
+
+def test_resampler_keeps_a_tone_and_its_level(tmp_path):
+    """wavio.resample_pcm / wav_to_adc(resample=True): a 440 Hz tone recorded at 44.1, 22.05, 16 and 11.025 kHz arrives at
+    8 kHz with its frequency, its amplitude (within 1 %) and its length; an 8 kHz file passes through untouched."""
+    for rate in (44100, 22050, 16000, 11025, 8000):
+        t = np.arange(int(rate * 0.5)) / rate
+        x = np.round(12000 * np.sin(2 * np.pi * 440 * t)).astype(np.int16)
+        path = str(tmp_path / f"tone_{rate}.wav")
+        with wave.open(path, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(rate)
+            w.writeframes(x.tobytes())
+        adc = wavio.wav_to_adc(path, expect_rate=8000, resample=True).astype(np.float64) - 2048
+        assert abs(len(adc) - 4000) <= 1
+        mid = adc[400:3600]
+        spec = np.abs(np.fft.rfft(mid * np.hanning(len(mid))))
+        assert abs(np.argmax(spec) * 8000 / len(mid) - 440) < 4
+        assert abs(np.sqrt(2 * np.mean(mid ** 2)) - 12000 / 16) < 0.01 * 12000 / 16
+    import pytest
+    with pytest.raises(ValueError):
+        wavio.wav_to_adc(str(tmp_path / "tone_16000.wav"), expect_rate=8000)
