@@ -541,3 +541,51 @@ def test_delta_mfcc_definition(oracle, golden):
         num = (c(1) - c(-1)) + 2 * (c(2) - c(-2))
         want = (np.sign(num) * (np.abs(num) // 10)).astype(np.int16)
         assert np.array_equal(oracle.delta_mfcc(m.astype(np.int16), n), want), n
+
+
+def test_extension_fft512_is_a_dft_within_its_truncation_bound(oracle):
+    """EXTENSION (no reference counterpart): the 512-point transform the extension front end is defined by
+    (oracle/q15_fft.c: two ST-style 256-point radix-4 transforms + one truncating radix-2 pass) is the DFT / 512 of its
+    input up to the truncation of its five stages.  Bound: an output component of a radix-4 pass is a sum of three
+    floored terms (A>>2, X>>16 or X>>15 twice, .s:105-129), i.e. off by less than 3 LSB, sqrt(2)*3 as a complex number;
+    a later pass averages four such inputs with unit-modulus coefficients, so an earlier error reaches the output with
+    at most its own size: 4 passes * 4.25 = 17 LSB worst case, + 2 for the two floors of the radix-2 pass, + the Q14
+    coefficient rounding, which scales with the signal.  (The errors are one-sided floors of independent data: the
+    typical error is a few LSB, asserted as an RMS.)  Checked on random data at several levels, on real zero-padded
+    frames (the shape get_mfcc feeds), on impulses and on pure tones."""
+    import ctypes as C
+    L = oracle.L
+    rng = np.random.default_rng(31)
+
+    def run(re, im):
+        w = re.astype(np.int16).view(np.uint16).astype(np.uint32) | (im.astype(np.int16).view(np.uint16).astype(np.uint32) << 16)
+        out = np.zeros(512, dtype=np.uint32)
+        L.sr_oracle_q15_fft512(out.ctypes.data_as(C.c_void_p), np.ascontiguousarray(w).ctypes.data_as(C.c_void_p))
+        got = (out & 0xFFFF).astype(np.uint16).view(np.int16).astype(np.float64) + \
+            1j * (out >> 16).astype(np.uint16).view(np.int16).astype(np.float64)
+        want = np.fft.fft(re.astype(np.float64) + 1j * im.astype(np.float64)) / 512.0
+        return got, want
+
+    worst = 0.0
+    cases = []
+    for amp in (40, 900, 12000, 32767):
+        cases.append((rng.integers(-amp, amp + 1, 512), rng.integers(-amp, amp + 1, 512)))
+        re = np.zeros(512, np.int64)
+        re[:320] = rng.integers(-amp, amp + 1, 320)                      # a real, zero-padded frame
+        cases.append((re, np.zeros(512, np.int64)))
+    for pos in (0, 1, 255, 511):
+        re = np.zeros(512, np.int64)
+        re[pos] = 32767
+        cases.append((re, np.zeros(512, np.int64)))
+    for kbin in (1, 37, 128, 255):
+        t = np.arange(512)
+        cases.append((np.round(20000 * np.cos(2 * np.pi * kbin * t / 512)).astype(np.int64),
+                      np.round(20000 * np.sin(2 * np.pi * kbin * t / 512)).astype(np.int64)))
+    for re, im in cases:
+        got, want = run(np.asarray(re), np.asarray(im))
+        scale = max(np.abs(want).max(), 1.0)
+        err = np.abs(got - want)
+        assert err.max() <= 19.0 + 6e-4 * scale, (err.max(), scale)
+        assert np.sqrt((err ** 2).mean()) <= 5.0 + 3e-4 * scale, (np.sqrt((err ** 2).mean()), scale)
+        worst = max(worst, err.max() - 6e-4 * scale)
+    assert worst > 0.3                                                    # the bound is not vacuous: truncation is visible
