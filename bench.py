@@ -168,29 +168,38 @@ def main():
         # one launch covers B / launches utterances; stage[...] are per-launch durations (hipEvents on its stream)
         launches = stage["launches_per_call"]
         ach = by_mfcc * (B / launches) / (stage["mfcc"] * 1e-3) / 1e9
-        traffic = traffic_src = None
+        # the same kernel alone on the chip: ONE launch over all B utterances (the untimed extra pass)
+        ach_iso = by_mfcc * B / (stage_iso["mfcc"] * 1e-3) / 1e9
+        traffic = traffic_iso = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            try:  # PMC pass measured one launch over tj["B"] utterances; a launch here covers B / launches of them
+            try:  # the PMC passes measured one whole-batch launch over tj["B"] utterances; traffic scales with utterances
                 tj = json.load(open(tpath))
                 traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]
+                traffic_iso = tj["k_mfcc_hbm_bytes_per_launch"] * B / tj["B"]
                 traffic_src = tj.get("source")
             except Exception:
-                traffic = None
-        # what actually bounds the path: VALU issue.  Wave-level VALU instructions per utterance come from the committed
-        # PMC pass (SQ_INSTS_VALU, profiles/pmc_valu.json); every wave64 VALU instruction of this mix holds its SIMD for
-        # 4.05 cycles (SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU), so the ceiling is 1024 SIMDs * 2.4 GHz / 4 = 6.14e11 /s.
+                traffic = traffic_iso = None
+        # What actually bounds the path: VALU issue.  Measured directly on this chip (profiles/r02/VALU_ISSUE.md,
+        # profiles/valu_issue_ubench.hip): in a mixed instruction stream every wave64 VALU instruction holds its SIMD's
+        # issue port for 4 cycles (a transcendental for 8); the 2-cycle rate of simple ops needs a pure run of them, which
+        # these kernels never have.  Ceiling = 1024 SIMDs x 2.4 GHz / 4 issue slots per second; the slots a step needs come
+        # from the committed PMC pass (SQ_ACTIVE_INST_VALU = 4-cycle issue slots, profiles/pmc_valu.json).
         roofline_valu = None
         vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
         if args.workload == "ref" and os.path.exists(vpath):
             try:
                 vj = json.load(open(vpath))
-                per_utt = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
+                insts = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
+                slots = sum(v for k, v in vj.items() if k.endswith("_valu_slots_per_utt")) or insts
                 peak = 1024 * 2.4e9 / 4.0
-                achv = per_utt * B / (stage["total"] * 1e-3)
-                roofline_valu = {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "wave-instructions/s",
-                                 "frac": achv / peak, "valu_insts_per_utt": per_utt, "source": vj.get("source"),
-                                 "note": "derived: instruction counts from the committed PMC pass x this run's step time"}
+                achv = slots * B / (stage["total"] * 1e-3)
+                roofline_valu = {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "4-cycle issue slots/s",
+                                 "frac": achv / peak, "valu_slots_per_utt": slots, "valu_insts_per_utt": insts,
+                                 "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9, "source": vj.get("source"),
+                                 "rates_source": "profiles/r02/VALU_ISSUE.md (per-opcode s_memtime micro-benchmark)",
+                                 "note": "derived: slot counts from the committed PMC pass x this run's step time; the chip "
+                                         "clocks 2.3-2.4 GHz under this load, the ceiling assumes the nominal 2.4"}
             except Exception:
                 roofline_valu = None
         line = {
@@ -217,7 +226,14 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": by_mfcc * B / launches, "kernel_ms": stage["mfcc"],
                          "launches_per_step": launches, "utterances_per_launch": B / launches,
-                         "note": "path is integer-VALU-bound, not HBM-bound (DESIGN.md); fraction reported as mandated"},
+                         "isolated": {"achieved": ach_iso, "frac": ach_iso / HBM_PEAK_GBS, "kernel_ms": stage_iso["mfcc"],
+                                      "utterances_per_launch": B, "algorithmic_bytes_per_launch": by_mfcc * B,
+                                      "traffic": traffic_iso,
+                                      "note": "the same kernel alone on the chip: one launch over the whole batch (untimed "
+                                              "extra pass); this is the figure the rocprof 'whole batch' rows agree with"},
+                         "note": "achieved/frac: launches of the TIMED steps (B/launches utterances each, overlapping two other "
+                                 "chunks' kernels on other streams, so each launch owns only part of the chip); the path is "
+                                 "integer-VALU-bound, not HBM-bound (DESIGN.md 3.2): see roofline_valu"},
             "roofline_path": {"bytes_per_utt": by_path, "achieved": by_path * B / (stage["total"] * 1e-3) / 1e9,
                               "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "note": "whole step (all chunks, fork -> join on the launch stream)"},

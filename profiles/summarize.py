@@ -2,7 +2,8 @@
 
   python profiles/summarize.py <gpurun_out/profdir> <tag>   ->  profiles/<tag>_rocprof_summary.csv
                                                                 profiles/pmc_traffic.json  (read by bench.py)
-profdir layout: stats/*kernel_stats.csv and pmc_<COUNTER>/*counter_collection.csv (one dir per --pmc pass).
+profdir layout: stats/*kernel_stats.csv, pmc_<COUNTER>/*counter_collection.csv (one dir per --pmc pass, every SQ pass
+also carrying GRBM_GUI_ACTIVE) and traffic_<batch>_<COUNTER>/ (FETCH_SIZE / WRITE_SIZE at a smaller batch).
 Only the engine's own kernels (sr::*) are kept; torch's data-generation kernels are dropped.
 HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE
 reports half of a coalesced stream, hence hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -47,7 +48,7 @@ def main():
         out.append(f"\"{k}\",whole batch,{len(whole)},{sum(whole) / len(whole):.0f}")
     out += ["", "# PMC passes (each its own run: rocprofv3 --kernel-trace --pmc <counters>), LAST launch = the whole-batch pass",
             "kernel,counter,value"]
-    vals, durs = {}, {}
+    vals, cyc = {}, {}
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         fs = glob.glob(os.path.join(d, "*counter_collection.csv"))
         if not fs:
@@ -56,47 +57,71 @@ def main():
         for r in csv.DictReader(open(fs[0])):
             if "sr::" in r["Kernel_Name"]:
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
-                acc[name][r["Counter_Name"]] = float(r["Counter_Value"])
-                durs[(name, r["Counter_Name"])] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])  # ns, this pass
+                acc[name][r["Counter_Name"]] = float(r["Counter_Value"])     # last launch wins = the whole-batch pass
         for k in acc:
             for c, v in sorted(acc[k].items()):
-                out.append(f"{k},{c},{v:.0f}")
+                if c != "GRBM_GUI_ACTIVE" or (k, c) not in vals:
+                    out.append(f"{k},{c},{v:.0f}")
                 vals[(k, c)] = v
-    # derived: VALU issue utilisation = SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) * 4 / (SIMDs * kernel cycles)
-    out += ["", "# derived (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; every counter is normalised with the",
-            "# duration of ITS OWN pass and the shader clock = GRBM_GUI_ACTIVE/8 / duration of the GRBM pass)", "kernel,metric,value"]
+                if "GRBM_GUI_ACTIVE" in acc[k]:
+                    cyc[(k, c)] = acc[k]["GRBM_GUI_ACTIVE"] / 8.0      # shader cycles of THIS pass (counter sums the 8 XCDs)
+    # derived.  SQ_ACTIVE_INST_VALU counts issue slots of 4 cycles ("quad-cycles"; a transcendental takes two): it equals
+    # SQ_INSTS_VALU + the transcendentals, which is what profiles/r02/VALU_ISSUE.md measured directly.  Busy fraction =
+    # slots * 4 / (1024 SIMDs * shader cycles of the same pass).
+    out += ["", "# derived (1024 SIMDs, 256 CUs; each fraction uses the GRBM_GUI_ACTIVE / 8 shader cycles of the pass its counter came from)",
+            "kernel,metric,value"]
     for k in ("sr::k_mfcc", "sr::k_dtw_lds", "sr::k_vad"):
         try:
-            clk = vals[(k, "GRBM_GUI_ACTIVE")] / 8.0 / durs[(k, "GRBM_GUI_ACTIVE")]  # cycles per ns
-            out.append(f"{k},shader_clock_ghz,{clk:.3f}")
-            cyc = clk * durs[(k, "SQ_ACTIVE_INST_VALU")]
-            busy = vals[(k, "SQ_ACTIVE_INST_VALU")] * 4.0 / (1024.0 * cyc)
-            out.append(f"{k},valu_busy_fraction,{busy:.3f}")
-            out.append(f"{k},cycles_per_valu_inst,{vals[(k, 'SQ_ACTIVE_INST_VALU')] * 4.0 / vals[(k, 'SQ_INSTS_VALU')]:.2f}")
+            c_v = cyc[(k, "SQ_ACTIVE_INST_VALU")]
+            out.append(f"{k},shader_cycles,{c_v:.0f}")
+            out.append(f"{k},valu_issue_busy_fraction,{min(1.0, vals[(k, 'SQ_ACTIVE_INST_VALU')] * 4.0 / (1024.0 * c_v)):.3f}")
+            out.append(f"{k},issue_slots_per_valu_inst,{vals[(k, 'SQ_ACTIVE_INST_VALU')] / vals[(k, 'SQ_INSTS_VALU')]:.3f}")
             if (k, "SQ_LDS_IDX_ACTIVE") in vals:
-                out.append(f"{k},lds_busy_fraction,{vals[(k, 'SQ_LDS_IDX_ACTIVE')] / (256.0 * cyc):.3f}")
+                c_l = cyc[(k, "SQ_LDS_IDX_ACTIVE")]
+                out.append(f"{k},lds_busy_fraction,{min(1.0, vals[(k, 'SQ_LDS_IDX_ACTIVE')] / (256.0 * c_l)):.3f}")
                 out.append(f"{k},lds_conflict_fraction,{vals[(k, 'SQ_LDS_BANK_CONFLICT')] / max(1.0, vals[(k, 'SQ_LDS_IDX_ACTIVE')]):.3f}")
+            if (k, "SQ_WAVE_CYCLES") in vals:
+                out.append(f"{k},mean_waves_per_simd,{vals[(k, 'SQ_WAVE_CYCLES')] * 4.0 / (1024.0 * cyc[(k, 'SQ_WAVE_CYCLES')]):.2f}")
         except KeyError:
             pass
     if ("sr::k_mfcc", "SQ_INSTS_VALU") in vals:
         out.append(f"sr::k_mfcc,valu_insts_per_frame,{vals[('sr::k_mfcc', 'SQ_INSTS_VALU')] / (65536 * 256.0):.1f}")
-    open(os.path.join(here, f"{tag}_rocprof_summary.csv"), "w").write("\n".join(out) + "\n")
-    if ("sr::k_mfcc", "FETCH_SIZE") in vals:
-        fs_, ws = vals[("sr::k_mfcc", "FETCH_SIZE")], vals[("sr::k_mfcc", "WRITE_SIZE")]
-        j = {"source": f"profiles/{tag}_rocprof_summary.csv", "kernel": "sr::k_mfcc", "B": 65536,
+    if ("sr::k_dtw_lds", "SQ_INSTS_VALU") in vals:
+        out.append(f"sr::k_dtw_lds,valu_insts_per_utt,{vals[('sr::k_dtw_lds', 'SQ_INSTS_VALU')] / 65536.0:.0f}")
+    # HBM traffic of k_mfcc: FETCH_SIZE / WRITE_SIZE passes at the smaller batch encoded in the directory name; the
+    # last k_mfcc launch of the run is bench.py's whole-batch pass (all tb utterances in one launch)
+    tr = {}
+    for d in sorted(glob.glob(os.path.join(root, "traffic_*"))):
+        tb = int(os.path.basename(d).split("_")[1])
+        fs = glob.glob(os.path.join(d, "*counter_collection.csv"))
+        if not fs:
+            continue
+        for r in csv.DictReader(open(fs[0])):
+            if "sr::k_mfcc" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                tr[r["Counter_Name"]] = (float(r["Counter_Value"]), tb)
+    if len(tr) == 2:
+        (fs_, tb), (ws, _) = tr["FETCH_SIZE"], tr["WRITE_SIZE"]
+        out += ["", f"# HBM traffic of the whole-batch k_mfcc launch at B = {tb} (separate --pmc passes; KB)",
+                "kernel,counter,value", f"sr::k_mfcc,FETCH_SIZE,{fs_:.1f}", f"sr::k_mfcc,WRITE_SIZE,{ws:.1f}"]
+        j = {"source": f"profiles/{tag}_rocprof_summary.csv", "kernel": "sr::k_mfcc", "B": tb,
              "FETCH_SIZE_KB": fs_, "WRITE_SIZE_KB": ws,
-             "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM section)",
+             "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM section; the factor 2 was "
+                           "re-calibrated for this kernel's access pattern, profiles/r02/VALU_ISSUE.md)",
              "k_mfcc_hbm_bytes_per_launch": int((2 * fs_ + ws) * 1024)}
         json.dump(j, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
     # VALU wave-instructions per utterance of the three big kernels (whole-batch launch, B = 65536): bench.py prices
     # a step against the VALU issue ceiling with these
-    vj = {"source": f"profiles/{tag}_rocprof_summary.csv", "B": 65536, "counter": "SQ_INSTS_VALU (wave-level instructions)"}
+    vj = {"source": f"profiles/{tag}_rocprof_summary.csv", "B": 65536,
+          "counter": "SQ_INSTS_VALU (wave-level instructions) and SQ_ACTIVE_INST_VALU (4-cycle issue slots: transcendentals count twice)"}
     for k in ("sr::k_vad", "sr::k_mfcc", "sr::k_dtw_lds", "sr::k_argmin"):
         if (k, "SQ_INSTS_VALU") in vals:
             vj[k.split("::")[1] + "_valu_insts_per_utt"] = vals[(k, "SQ_INSTS_VALU")] / 65536.0
+        if (k, "SQ_ACTIVE_INST_VALU") in vals:
+            vj[k.split("::")[1] + "_valu_slots_per_utt"] = vals[(k, "SQ_ACTIVE_INST_VALU")] / 65536.0
     if len(vj) > 3:
         json.dump(vj, open(os.path.join(here, "pmc_valu.json"), "w"), indent=1)
-    print("\n".join(out[-14:]))
+    open(os.path.join(here, f"{tag}_rocprof_summary.csv"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out[-24:]))
 
 
 if __name__ == "__main__":

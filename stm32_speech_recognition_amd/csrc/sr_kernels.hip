@@ -642,7 +642,11 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 namespace ext {
 constexpr int kFL = 320, kHopE = 160, kBinsE = 256, kMelE = 40;
 constexpr int kWaves = 4, kFpw = 8, kTile = kWaves * kFpw;
-constexpr int kWaveWords = 512 + 512 + kFpw * kMelE;  // two 256-word sub-arrays, scratch, filterbank outputs
+// pass outputs live at apad(j) = j + 4*(j >> 4) (20 words per 16): with lane = (j / q) stride patterns of the q = 4 and
+// q = 16 passes that makes every 32-lane access group hit 32 different banks (plain addressing: 8-way conflicts at q = 4)
+constexpr int kSubWords = 320;                              // one padded 256-point sub-array
+constexpr int kWaveWords = 512 + 2 * kSubWords + kFpw * kMelE;  // windowed samples, two padded sub-arrays, filterbank outputs
+__device__ __forceinline__ int apad(int j) { return j + ((j >> 4) << 2); }
 }  // namespace ext
 
 __device__ __forceinline__ int bitrev6(int v) { return (int)(__brev((uint32_t)v) >> 26); }
@@ -656,8 +660,8 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
     __shared__ uint16_t s_hamm[kFL];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *work = smem + w * kWaveWords;  // [2][256] packed samples of the even / odd sub-transform
-    uint32_t *aux = work + 512;              // [2][256] pass outputs, later prefix sums
-    uint32_t *powb = aux + 512;
+    uint32_t *aux = work + 512;              // [2][320] pass outputs at apad(j), later prefix sums
+    uint32_t *powb = aux + 2 * kSubWords;
     for (int i = threadIdx.x; i < kCoef * kMelE; i += blockDim.x) {
         const int c = a.t.dct[i];
         s_dctM[i] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
@@ -731,11 +735,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
                 const int br = (int)(wb << 16) >> 2, cr = (int)(wc << 16) >> 2;
                 uint32_t x0, x1, x2, x3;
                 r4_packed<false, true, true>(wa, br, 0, cr, 0, cr, 0, x0, x1, x2, x3);
-                uint32_t *dst = aux + sub * 256 + 4 * lane;
-                dst[0] = x0;
-                dst[1] = x1;
-                dst[2] = x2;
-                dst[3] = x3;
+                *(u32x4 *)(aux + sub * kSubWords + apad(4 * lane)) = u32x4{x0, x1, x2, x3};  // 4 consecutive words of one 16-block
             }
             wave_sync();
             // passes 2-4 (q = 4, 16, 64) in place; coefficient blocks N = 16, 64, 256 of the ST table
@@ -745,14 +745,15 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
                 const int bq = lane & (q - 1), j = ((lane / q) * 4 * q) + bq;
 #pragma unroll
                 for (int sub = 0; sub < 2; sub++) {
-                    uint32_t *p = aux + sub * 256 + j;
-                    uint32_t x0 = p[0], x1 = p[q], x2 = p[2 * q], x3 = p[3 * q];
+                    uint32_t *p = aux + sub * kSubWords;
+                    const int a0 = apad(j), a1 = apad(j + q), a2 = apad(j + 2 * q), a3 = apad(j + 3 * q);
+                    uint32_t x0 = p[a0], x1 = p[a1], x2 = p[a2], x3 = p[a3];
                     bfly_pk<false>(x0, x1, x2, x3, kq[pass][0][0], kq[pass][0][1], kq[pass][1][0], kq[pass][1][1],
                                    kq[pass][2][0], kq[pass][2][1], kq[pass][3][0], kq[pass][3][1]);
-                    p[0] = x0;
-                    p[q] = x1;
-                    p[2 * q] = x2;
-                    p[3 * q] = x3;
+                    p[a0] = x0;
+                    p[a1] = x1;
+                    p[a2] = x2;
+                    p[a3] = x3;
                 }
                 wave_sync();
             }
@@ -760,7 +761,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int kb = lane + 64 * m;
-                const uint32_t e = aux[kb], o = aux[256 + kb];
+                const uint32_t e = aux[apad(kb)], o = aux[kSubWords + apad(kb)];
                 int pr, pi;
                 cxmul(o, a.t.w512_a[kb], a.t.w512_b[kb], pr, pi);
                 // (E + (P >> 14)) >> 1 == ((E << 14) + P) >> 15 (the dropped low bits of P are < 1/2); doubled once more
