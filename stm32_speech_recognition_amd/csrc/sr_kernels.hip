@@ -636,170 +636,283 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 // converts 1024 points (.s:214-215).  Same arithmetic rules as get_mfcc (MFCC.C:86-191) with the tables generated
 // from the same Matlab formulas at fs = 16000; the 512-point transform is two ST-style 256-point radix-4
 // transforms (even / odd samples) + one truncating radix-2 pass, as defined in oracle/q15_fft.c.
-// One wave per frame; every pass goes through LDS (64 radix-4 butterflies per 256-point pass = one per lane).
-// Correctness-first: this kernel is not tuned like k_mfcc.
+//
+// Register-resident like k_mfcc: a wave works on FOUR frames at once, 16 lanes per frame, each lane holding 16 points
+// of both 256-point sub-transforms.  With j = d0 + 4*d1 + 16*d2 + 64*d3 the index of a point after pass 1:
+//   layout A  lane = (d2, d3)  holds v[d0][d1]: passes 1 and 2 (digits d0 / d1) in registers.  Pass 1 reads
+//             src[bitrev6(j >> 2) + 64 m] = the samples i == 2*base (+1) (mod 32), base = rev2(d3) + 4*rev2(d2): exactly
+//             the 20 samples this lane windows itself, so there is no LDS gather at all; legs >= 160 are zero padding.
+//   exchange  one pass through LDS (element e = d0 + 4*d1 of lane l at e*65 + l: writes and reads conflict-free)
+//   layout B  lane = (d0, d1)  holds u[d2][d3]: passes 3 and 4 (digits d2 / d3) and the radix-2 pass E[k] +- O[k]W[k]
+//             (both sub-transforms of a bin live in the same lane) in registers, then |X|*10 and the energy.
+// The energies are transposed through LDS to 16 contiguous bins per lane for the filterbank prefix sums (row scans
+// over the frame's 16 lanes), log and DCT are batched over the wave's frames as in k_mfcc.
 // ------------------------------------------------------------------------------------------------
 namespace ext {
 constexpr int kFL = 320, kHopE = 160, kBinsE = 256, kMelE = 40;
-constexpr int kWaves = 4, kFpw = 8, kTile = kWaves * kFpw;
-// pass outputs live at apad(j) = j + 4*(j >> 4) (20 words per 16): with lane = (j / q) stride patterns of the q = 4 and
-// q = 16 passes that makes every 32-lane access group hit 32 different banks (plain addressing: 8-way conflicts at q = 4)
-constexpr int kSubWords = 320;                              // one padded 256-point sub-array
-constexpr int kWaveWords = 512 + 2 * kSubWords + kFpw * kMelE;  // windowed samples, two padded sub-arrays, filterbank outputs
-__device__ __forceinline__ int apad(int j) { return j + ((j >> 4) << 2); }
+constexpr int kWaves = 4, kGrp = 4, kFpw = 8, kTile = kWaves * kFpw;  // kGrp frames in flight per wave
+constexpr int kXStride = 65;                  // exchange image: element e of lane l at e*65 + l
+constexpr int kXSub = 16 * kXStride;          // one sub-transform
+constexpr int kXWords = 2 * kXSub;            // 2080; later reused for energies and prefix sums
+constexpr int kEStride = 336;                 // energies of one frame: bin k at k + 4*(k >> 4), frames 336 words apart
+constexpr int kWaveWords = kXWords + 2 * 16 * kGrp + kFpw * kMelE;  // + prefix lane offsets + filterbank outputs
+static_assert(kFL == 2 * 16 * 10, "a 16-lane frame group windows 10 sample pairs per lane");
+static_assert(kGrp * kEStride <= kXWords && kGrp * 2 * kBinsE <= kXWords, "energies / prefix sums reuse the exchange image");
 }  // namespace ext
 
-__device__ __forceinline__ int bitrev6(int v) { return (int)(__brev((uint32_t)v) >> 26); }
+// inclusive prefix sum inside each row of 16 lanes
+__device__ __forceinline__ uint32_t row_scan_incl(uint32_t v)
+{
+    v += dpp_take<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_take<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_take<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_take<0x118, 0xF>(v);  // row_shr:8
+    return v;
+}
 
-__global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
+__global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs a)
 {
     using namespace ext;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_dctM[kCoef * kMelE];  // same exact-division-by-100 device as k_mfcc (see there)
     __shared__ int s_dctS[kCoef * kMelE];
-    __shared__ uint16_t s_hamm[kFL];
+    __shared__ u32x4 s_tw4[8 * 16], s_w512[8 * 16], s_tri[8 * 16];  // per-lane constants of layout B, chunk c of lane l at [c*16 + l]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t *work = smem + w * kWaveWords;  // [2][256] packed samples of the even / odd sub-transform
-    uint32_t *aux = work + 512;              // [2][320] pass outputs at apad(j), later prefix sums
-    uint32_t *powb = aux + 2 * kSubWords;
+    const int g = lane >> 4, gl = lane & 15;
+    uint32_t *xb = smem + w * kWaveWords;
+    uint32_t *moff = xb + kXWords, *powb = moff + 2 * 16 * kGrp;
     for (int i = threadIdx.x; i < kCoef * kMelE; i += blockDim.x) {
         const int c = a.t.dct[i];
         s_dctM[i] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
         s_dctS[i] = (c > 0) - (c < 0);
     }
-    for (int i = threadIdx.x; i < kFL; i += blockDim.x) s_hamm[i] = a.t.hamm[i];
-    __syncthreads();
-
-    uint32_t tri_e[4], tri_o[4];  // triangle weights of bins 4*lane .. 4*lane+3
+    // ---- constants of layout A: lane = (d2, d3) --------------------------------------------------
+    const int base = rev2(gl >> 2) + 4 * rev2(gl & 3);
+    uint32_t hp[10];  // Hamming weights of the lane's sample pairs (2*base + 32 t, +1)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        tri_e[k] = a.t.tri_even[4 * lane + k];
-        tri_o[k] = a.t.tri_odd[4 * lane + k];
-    }
-    int f_lo = 0, f_hi = 0;
-    if (lane < kMelE) {
-        f_lo = (lane == 0) ? 0 : (int)a.t.tri_cen[lane - 1];
-        f_hi = (lane == kMelE - 1) ? kBinsE : (int)a.t.tri_cen[lane + 1];
-    }
-
-    // coefficients of passes 2-4 (q = 4, 16, 64: blocks N = 16, 64, 256 of the ST table) are lane-invariant:
-    // loaded once, third leg also negated (see bfly_pk)
-    uint32_t kq[3][4][2];
-    {
-        int tw_base = 0;
+    for (int t = 0; t < 10; t++) hp[t] = (uint32_t)a.t.hamm[2 * base + 32 * t] | ((uint32_t)a.t.hamm[2 * base + 32 * t + 1] << 16);
+    // ---- constants of layout B: lane = (d0, d1), j = gl + 16*d2 + 64*d3 ----------------------------
+    uint32_t k3[4][2];  // pass 3 (q = 16, coefficient block N = 64): index j & 15 = gl
+    load_tw4(a.t, 12, gl, k3);
+    if (w == 0 && lane < 16) {  // pass 4 (q = 64, block N = 256): index j & 63 = gl + 16*d2
 #pragma unroll
-        for (int pass = 0; pass < 3; pass++) {
-            const int q = 4 << (2 * pass);
-            load_tw4(a.t, tw_base, lane & (q - 1), kq[pass]);
-            tw_base += 3 * q;
+        for (int d2 = 0; d2 < 4; d2++) {
+            uint32_t k[4][2];
+            load_tw4(a.t, 60, gl + 16 * d2, k);
+            s_tw4[(2 * d2) * 16 + gl] = u32x4{k[0][0], k[0][1], k[1][0], k[1][1]};
+            s_tw4[(2 * d2 + 1) * 16 + gl] = u32x4{k[2][0], k[2][1], k[3][0], k[3][1]};
         }
     }
+    if (w == 1 % kWaves && lane < 16) {  // radix-2 coefficients of the lane's bins k = gl + 16 m
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int k0 = gl + 16 * (2 * c), k1 = gl + 16 * (2 * c + 1);
+            s_w512[c * 16 + gl] = u32x4{a.t.w512_a[k0], a.t.w512_b[k0], a.t.w512_a[k1], a.t.w512_b[k1]};
+        }
+    }
+    if (w == 2 % kWaves && lane < 16) {  // triangle weights of the bins 16*gl .. 16*gl + 15 (filterbank layout)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int b0 = 16 * gl + 2 * c;
+            s_tri[c * 16 + gl] = u32x4{a.t.tri_even[b0], a.t.tri_odd[b0], a.t.tri_even[b0 + 1], a.t.tri_odd[b0 + 1]};
+        }
+    }
+    // filters h = gl, gl + 16, gl + 32 (< 40) of the lane's frame: bins [lo, hi) of poly-line h & 1 (MFCC.C:136-162)
+    int f_lo[3], f_hi[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int h = gl + 16 * q;
+        f_lo[q] = (h == 0 || h >= kMelE) ? 0 : (int)a.t.tri_cen[h - 1];
+        f_hi[q] = (h >= kMelE) ? 1 : (h == kMelE - 1) ? kBinsE : (int)a.t.tri_cen[h + 1];
+    }
+    __syncthreads();
 
+    // Work items are (utterance, tile of kTile frames); the records of the next two items are read ahead, and the
+    // samples of the NEXT batch of four frames (same item, or the first batch of the next item that has frames) are
+    // requested before the current batch is transformed, so the loads have a whole batch of arithmetic to land.
+    struct Item {
+        const uint16_t *x0;  // first sample of the wave's first frame
+        int mid;
+        uint32_t nf;         // frames this wave has in the item
+    };
+    auto item_info = [&](uint32_t it) {
+        Item r{nullptr, 0, 0u};
+        if (it < a.n_items) {
+            const uint32_t bb = it / a.tiles, tl = it - bb * a.tiles;
+            const sr_vad_rec *rec = a.vad + bb;
+            const uint32_t nfrm = rec->frm_num, ff = tl * kTile + w * kFpw;
+            r.mid = (int)rec->atap.mid_val;
+            r.x0 = a.pcm + (uint64_t)bb * a.pcm_stride + rec->seg[0] + kHopE * (int)ff;
+            if (ff < nfrm) r.nf = (nfrm - ff < (uint32_t)kFpw) ? nfrm - ff : (uint32_t)kFpw;
+        }
+        return r;
+    };
+    uint32_t qa[10], qb[10];  // pending sample pairs: x[i-1] | x[i] << 16 for i = 2*base + 32 t and i + 1
+    uint32_t q_item = 0xFFFFFFFFu, q_fb = 0;
+    auto fetch = [&](const Item &it, uint32_t it_id, uint32_t fb) {
+        const uint32_t fi = fb + (uint32_t)g;
+        const uint16_t *x = it.x0 + kHopE * (int)(fi < it.nf ? fi : it.nf - 1);  // groups past the last frame redo it
+#pragma unroll
+        for (int t = 0; t < 10; t++) {
+            const int i0 = 2 * base + 32 * t;
+            qa[t] = *(const u32_align2 *)(x + i0 - 1);
+            qb[t] = *(const u32_align2 *)(x + i0);
+        }
+        q_item = it_id;
+        q_fb = fb;
+    };
+    Item cur = item_info(blockIdx.x), nx1 = item_info(blockIdx.x + gridDim.x), nx2 = item_info(blockIdx.x + 2 * gridDim.x);
+    if (cur.nf) fetch(cur, blockIdx.x, 0);
     for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         const uint32_t b = item / a.tiles, tile = item - b * a.tiles;
-        const sr_vad_rec *rec = a.vad + b;
-        const uint32_t nfrm = rec->frm_num;
-        const int mid = (int)rec->atap.mid_val, seg0 = rec->seg[0];
-        const uint16_t *row = a.pcm + (uint64_t)b * a.pcm_stride;
         int16_t *out = a.mfcc + (uint64_t)b * a.max_frames * kCoef;
         const uint32_t f0 = tile * kTile + w * kFpw;
-        uint32_t nf = 0;
-        if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFpw) ? nfrm - f0 : (uint32_t)kFpw;
+        const uint32_t nf = cur.nf;
+        const int mid = cur.mid;
 
-        for (uint32_t fi = 0; fi < nf; fi++) {
-            const uint16_t *x = row + seg0 + kHopE * (int)(f0 + fi);
-            // pre-emphasis + Hamming (MFCC.C:115-124); sample i goes to sub-array i&1, slot i>>1; rest zero
+        for (uint32_t fb = 0; fb < nf; fb += kGrp) {
+            const uint32_t fi = fb + (uint32_t)g;
+            const bool live = fi < nf;
+            if (!(q_item == item && q_fb == fb)) fetch(cur, item, fb);  // not read ahead (first batch after a run of empty items)
+            uint32_t pa[10], pb[10];
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int i = lane + 64 * k;
-                const uint32_t pp = *(const u32_align2 *)(x + i - 1);  // x[i-1] | x[i] << 16
-                const int cur = (int)(pp >> 16) - mid, prv = (int)(pp & 0xFFFFu) - mid;
-                const int t = cur - mul24(prv, 95) / 100;
-                work[(i & 1) * 256 + (i >> 1)] = (uint32_t)(t * (int)s_hamm[i] / 1000) & 0xFFFFu;
+            for (int t = 0; t < 10; t++) {
+                pa[t] = qa[t];
+                pb[t] = qb[t];
             }
+            if (fb + kGrp < nf) fetch(cur, item, fb + kGrp);
+            else if (nx1.nf) fetch(nx1, item + gridDim.x, 0);
+            else if (nx2.nf) fetch(nx2, item + 2 * gridDim.x, 0);
+            // ---- pre-emphasis + Hamming (MFCC.C:115-124) of the lane's 20 samples: pairs (2*base + 32 t, +1), t < 10;
+            //      the even one belongs to sub-transform 0 (slot base + 16 t), the odd one to sub-transform 1
+            uint32_t ws[2][10];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int z = lane + 64 * k;  // 2 x 96 padding words
-                work[(z / 96) * 256 + 160 + (z % 96)] = 0u;
+            for (int t = 0; t < 10; t++) {
+                const int c0 = (int)(pa[t] >> 16) - mid, p0 = (int)(pa[t] & 0xFFFFu) - mid;
+                const int c1 = (int)(pb[t] >> 16) - mid, p1 = (int)(pb[t] & 0xFFFFu) - mid;
+                const int t0 = c0 - mul24(p0, 95) / 100, t1 = c1 - mul24(p1, 95) / 100;
+                ws[0][t] = (uint32_t)(mul24(t0, (int)(hp[t] & 0xFFFFu)) / 1000) & 0xFFFFu;
+                ws[1][t] = (uint32_t)(mul24(t1, (int)(hp[t] >> 16)) / 1000) & 0xFFFFu;
             }
-            wave_sync();
-            // pass 1 of both 256-point transforms: work -> aux (bit-reversed gather, legs 64 words apart)
+            // ---- passes 1 and 2 of both sub-transforms in registers, then the exchange image
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                const uint32_t *src = work + sub * 256;
-                const int r = bitrev6(lane);
-                // real samples (imaginary halves 0); leg D = src[r + 192] is always zero padding (slots >= 160), so
-                // C' = D' = C.  The S = 0 combine of BUTFLY4ZERO_OPT (.s:147-168) is the packed S = 14 combine on the
-                // samples scaled by 2^14: (x << 14) >> 16 = x >> 2, (x << 14) >> 15 = x >> 1.
-                const uint32_t wa = src[r], wc = src[r + 64], wb = src[r + 128];
-                const int br = (int)(wb << 16) >> 2, cr = (int)(wc << 16) >> 2;
-                uint32_t x0, x1, x2, x3;
-                r4_packed<false, true, true>(wa, br, 0, cr, 0, cr, 0, x0, x1, x2, x3);
-                *(u32x4 *)(aux + sub * kSubWords + apad(4 * lane)) = u32x4{x0, x1, x2, x3};  // 4 consecutive words of one 16-block
-            }
-            wave_sync();
-            // passes 2-4 (q = 4, 16, 64) in place; coefficient blocks N = 16, 64, 256 of the ST table
+                uint32_t v[4][4];  // [d0][d1]
 #pragma unroll
-            for (int pass = 0; pass < 3; pass++) {
-                const int q = 4 << (2 * pass);
-                const int bq = lane & (q - 1), j = ((lane / q) * 4 * q) + bq;
-#pragma unroll
-                for (int sub = 0; sub < 2; sub++) {
-                    uint32_t *p = aux + sub * kSubWords;
-                    const int a0 = apad(j), a1 = apad(j + q), a2 = apad(j + 2 * q), a3 = apad(j + 3 * q);
-                    uint32_t x0 = p[a0], x1 = p[a1], x2 = p[a2], x3 = p[a3];
-                    bfly_pk<false>(x0, x1, x2, x3, kq[pass][0][0], kq[pass][0][1], kq[pass][1][0], kq[pass][1][1],
-                                   kq[pass][2][0], kq[pass][2][1], kq[pass][3][0], kq[pass][3][1]);
-                    p[a0] = x0;
-                    p[a1] = x1;
-                    p[a2] = x2;
-                    p[a3] = x3;
+                for (int d1 = 0; d1 < 4; d1++) {
+                    // butterfly idx = d1 + 4*d2 + 16*d3 reads src[r], src[r+64], src[r+128], src[r+192] (A, C, B, D as in
+                    // .s:134-145) with r = bitrev6(idx) = base + 16*rev2(d1): slots t = rev2(d1), +4, +8; D (and B when
+                    // r + 128 >= 160) is zero padding.  Real samples: the S = 0 combine of BUTFLY4ZERO_OPT (.s:147-168)
+                    // is the packed S = 14 combine on the samples scaled by 2^14 ((x << 14) >> 16 = x >> 2).
+                    const int rd = ((d1 & 1) << 1) | (d1 >> 1);
+                    const uint32_t wa = ws[sub][rd], wc = ws[sub][4 + rd];
+                    const int cr = (int)(wc << 16) >> 2;
+                    if (rd < 2) {
+                        const int br = (int)(ws[sub][8 + rd] << 16) >> 2;
+                        r4_packed<false, true, true>(wa, br, 0, cr, 0, cr, 0, v[0][d1], v[1][d1], v[2][d1], v[3][d1]);
+                    } else {
+                        r4_packed<false, false, true>(wa, 0, 0, cr, 0, cr, 0, v[0][d1], v[1][d1], v[2][d1], v[3][d1]);
+                    }
                 }
-                wave_sync();
-            }
-            // radix-2 pass for bins < 256: X[k] = (E[k] + O[k]*conj(W[k]) >> 14) >> 1, then |X|*10 and energy
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int kb = lane + 64 * m;
-                const uint32_t e = aux[apad(kb)], o = aux[kSubWords + apad(kb)];
-                int pr, pi;
-                cxmul(o, a.t.w512_a[kb], a.t.w512_b[kb], pr, pi);
-                // (E + (P >> 14)) >> 1 == ((E << 14) + P) >> 15 (the dropped low bits of P are < 1/2); doubled once more
-                // so that the wanted 16 bits are the high halves, packed by one v_perm and squared by one dot product
-                const int t_re = (int)(((uint32_t)((int)(e << 16) >> 1)) + ((uint32_t)pr << 1));
-                const int t_im = (int)(((uint32_t)((int)(e & 0xFFFF0000u) >> 1)) + ((uint32_t)pi << 1));
-                const uint32_t xk = pk_hi16(t_re, t_im);  // (re, im) of X[k] as stored 16-bit values
-                const uint32_t mag = (uint32_t)(sqrt_rn_int((float)sdot2z(xk, xk)) * 10.0f);
-                work[kb] = mag * mag;
+                for (int d0 = 0; d0 < 4; d0++) {  // pass 2 (q = 4, block N = 16): coefficient index j & 3 = d0, lane-invariant
+                    uint32_t k2[4][2];
+                    load_tw4(a.t, 0, d0, k2);
+                    bfly_pk<false>(v[d0][0], v[d0][1], v[d0][2], v[d0][3], k2[0][0], k2[0][1], k2[1][0], k2[1][1], k2[2][0],
+                                   k2[2][1], k2[3][0], k2[3][1]);
+                }
+#pragma unroll
+                for (int d1 = 0; d1 < 4; d1++)
+#pragma unroll
+                    for (int d0 = 0; d0 < 4; d0++) xb[sub * kXSub + (d0 + 4 * d1) * kXStride + lane] = v[d0][d1];
             }
             wave_sync();
-            // Mel filterbank via prefix sums (MFCC.C:136-162 at 40 filters / 256 bins)
-            uint32_t pe[4], po[4];
+            uint32_t u[2][4][4];  // [sub][d2][d3], lane = (d0, d1) = gl
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                for (int d3 = 0; d3 < 4; d3++)
+#pragma unroll
+                    for (int d2 = 0; d2 < 4; d2++) u[sub][d2][d3] = xb[sub * kXSub + gl * kXStride + d2 + 4 * d3 + 16 * g];
+            // ---- passes 3 (q = 16) and 4 (q = 64)
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+                for (int d3 = 0; d3 < 4; d3++)
+                    bfly_pk<false>(u[sub][0][d3], u[sub][1][d3], u[sub][2][d3], u[sub][3][d3], k3[0][0], k3[0][1], k3[1][0],
+                                   k3[1][1], k3[2][0], k3[2][1], k3[3][0], k3[3][1]);
+#pragma unroll
+            for (int d2 = 0; d2 < 4; d2++) {
+                const u32x4 ka = s_tw4[(2 * d2) * 16 + gl], kb = s_tw4[(2 * d2 + 1) * 16 + gl];
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++)
+                    bfly_pk<false>(u[sub][d2][0], u[sub][d2][1], u[sub][d2][2], u[sub][d2][3], ka.x, ka.y, ka.z, ka.w, kb.x, kb.y,
+                                   kb.z, kb.w);
+            }
+            wave_sync();  // the exchange image has been consumed by every lane: reuse it for the energies
+            // ---- radix-2 pass for bins k = gl + 16 m < 256, |X|*10, energy
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const u32x4 wq = s_w512[c * 16 + gl];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const int m = 2 * c + h2, d2 = m & 3, d3 = m >> 2;
+                    const uint32_t e = u[0][d2][d3], o = u[1][d2][d3];
+                    int pr, pi;
+                    cxmul(o, h2 ? wq.z : wq.x, h2 ? wq.w : wq.y, pr, pi);
+                    // (E + (P >> 14)) >> 1 == ((E << 14) + P) >> 15 (the dropped low bits of P are < 1/2); doubled once more
+                    // so that the wanted 16 bits are the high halves, packed by one v_perm and squared by one dot product
+                    const int t_re = (int)(((uint32_t)((int)(e << 16) >> 1)) + ((uint32_t)pr << 1));
+                    const int t_im = (int)(((uint32_t)((int)(e & 0xFFFF0000u) >> 1)) + ((uint32_t)pi << 1));
+                    const uint32_t xk = pk_hi16(t_re, t_im);  // (re, im) of X[k] as stored 16-bit values
+                    const uint32_t mag = (uint32_t)(sqrt_rn_int((float)sdot2z(xk, xk)) * 10.0f);
+                    xb[g * kEStride + gl + 20 * m] = mag * mag;  // bin k = gl + 16 m at k + 4*(k >> 4)
+                }
+            }
+            wave_sync();
+            // ---- Mel filterbank via prefix sums (MFCC.C:136-162 at 40 filters / 256 bins): this lane owns the 16
+            //      contiguous bins 16*gl .. of its frame
+            uint32_t pe[16], po[16], xe, xo;
             {
-                const u32x4 q0 = *(const u32x4 *)(work + 4 * lane);
-                const uint32_t e[4] = {q0.x, q0.y, q0.z, q0.w};
                 uint32_t se = 0, so = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    se += e[k] * tri_e[k] / 100u;
-                    so += e[k] * tri_o[k] / 100u;
-                    pe[k] = se;
-                    po[k] = so;
-                }
-                const uint32_t xe = wave_scan_incl(se) - se, xo = wave_scan_incl(so) - so;
+                for (int c = 0; c < 4; c++) {
+                    const u32x4 q = *(const u32x4 *)(xb + g * kEStride + 20 * gl + 4 * c);
+                    const uint32_t e4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    pe[k] += xe;
-                    po[k] += xo;
+                    for (int h2 = 0; h2 < 2; h2++) {
+                        const u32x4 tq = s_tri[(2 * c + h2) * 16 + gl];  // (even, odd) weights of two bins
+                        se += e4[2 * h2] * tq.x / 100u;
+                        so += e4[2 * h2] * tq.y / 100u;
+                        pe[4 * c + 2 * h2] = se;
+                        po[4 * c + 2 * h2] = so;
+                        se += e4[2 * h2 + 1] * tq.z / 100u;
+                        so += e4[2 * h2 + 1] * tq.w / 100u;
+                        pe[4 * c + 2 * h2 + 1] = se;
+                        po[4 * c + 2 * h2 + 1] = so;
+                    }
                 }
+                xe = row_scan_incl(se) - se;  // bins of the frame's lower lanes
+                xo = row_scan_incl(so) - so;
             }
-            *(u32x4 *)(aux + 4 * lane) = u32x4{pe[0], pe[1], pe[2], pe[3]};
-            *(u32x4 *)(aux + kBinsE + 4 * lane) = u32x4{po[0], po[1], po[2], po[3]};
             wave_sync();
-            if (lane < kMelE) {
-                const uint32_t *P = aux + ((lane & 1) ? kBinsE : 0);
-                const uint32_t hi = P[f_hi - 1], lo = f_lo ? P[f_lo - 1] : 0u;
-                powb[fi * kMelE + lane] = hi - lo;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                *(u32x4 *)(xb + g * 512 + 16 * gl + 4 * c) = u32x4{pe[4 * c], pe[4 * c + 1], pe[4 * c + 2], pe[4 * c + 3]};
+                *(u32x4 *)(xb + g * 512 + 256 + 16 * gl + 4 * c) = u32x4{po[4 * c], po[4 * c + 1], po[4 * c + 2], po[4 * c + 3]};
+            }
+            moff[g * 32 + gl] = xe;
+            moff[g * 32 + 16 + gl] = xo;
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int h = gl + 16 * q;
+                if (h < kMelE) {
+                    const uint32_t *P = xb + g * 512 + ((h & 1) ? 256 : 0), *X = moff + g * 32 + ((h & 1) ? 16 : 0);
+                    const int ih = f_hi[q] - 1, il = f_lo[q] - 1;
+                    const uint32_t hi = P[ih] + X[ih >> 4], lo = f_lo[q] ? P[il] + X[il >> 4] : 0u;
+                    if (live) powb[fi * kMelE + h] = hi - lo;
+                }
             }
             wave_sync();
         }
@@ -818,6 +931,9 @@ __global__ void __launch_bounds__(64 * ext::kWaves) k_mfcc_ext(const MfccArgs a)
             const uint32_t r0 = f0 + nf, r1 = (f0 + kFpw < a.max_frames) ? f0 + kFpw : a.max_frames;
             for (uint32_t t = r0 * kCoef + lane; t < r1 * kCoef && r0 < r1; t += 64) out[t] = 0;
         }
+        cur = nx1;
+        nx1 = nx2;
+        nx2 = item_info(item + 3 * gridDim.x);
     }
 }
 
