@@ -172,7 +172,7 @@ def main():
         ach_iso = by_mfcc * B / (stage_iso["mfcc"] * 1e-3) / 1e9
         traffic = traffic_iso = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if args.workload == "ref" and os.path.exists(tpath):
             try:  # the PMC passes measured one whole-batch launch over tj["B"] utterances; traffic scales with utterances
                 tj = json.load(open(tpath))
                 traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]

@@ -1,7 +1,8 @@
 """Turn rocprofv3 CSV output (kernel stats + separate --pmc passes) into the committed summaries.
 
-  python profiles/summarize.py <gpurun_out/profdir> <tag>   ->  profiles/<tag>_rocprof_summary.csv
-                                                                profiles/pmc_traffic.json  (read by bench.py)
+  python profiles/summarize.py <gpurun_out/profdir> <tag> [batch] [description]
+        ->  profiles/<tag>_rocprof_summary.csv, and for the reference workload (no description given)
+            profiles/pmc_traffic.json + profiles/pmc_valu.json  (read by bench.py)
 profdir layout: stats/*kernel_stats.csv, pmc_<COUNTER>/*counter_collection.csv (one dir per --pmc pass, every SQ pass
 also carrying GRBM_GUI_ACTIVE) and traffic_<batch>_<COUNTER>/ (FETCH_SIZE / WRITE_SIZE at a smaller batch).
 Only the engine's own kernels (sr::*) are kept; torch's data-generation kernels are dropped.
@@ -18,8 +19,11 @@ import sys
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    desc = sys.argv[4] if len(sys.argv) > 4 else None
     here = os.path.dirname(os.path.abspath(__file__))
-    out = [f"# rocprofv3 summary {tag}: python bench.py --steps 5 --warmup 1 --no-cpu-baseline on 1x MI355X (B=65536, K=100, T=256)",
+    out = [f"# rocprofv3 summary {tag}: python bench.py --steps 5 --warmup 1 --no-cpu-baseline on 1x MI355X "
+           + (desc if desc else f"(B={batch}, K=100, T=256)"),
            "# rocprofv3 --kernel-trace --stats --output-format csv   (all launches mixed: template pass, chunks, whole-batch pass)",
            "kernel,calls,avg_ns,min_ns,max_ns,pct"]
     for f in glob.glob(os.path.join(root, "stats", "*kernel_stats.csv")):
@@ -70,7 +74,9 @@ def main():
     # slots * 4 / (1024 SIMDs * shader cycles of the same pass).
     out += ["", "# derived (1024 SIMDs, 256 CUs; each fraction uses the GRBM_GUI_ACTIVE / 8 shader cycles of the pass its counter came from)",
             "kernel,metric,value"]
-    for k in ("sr::k_mfcc", "sr::k_dtw_lds", "sr::k_vad"):
+    for k in sorted(set(kk for kk, _ in vals)):
+        if k == "sr::k_argmin":
+            continue
         try:
             c_v = cyc[(k, "SQ_ACTIVE_INST_VALU")]
             out.append(f"{k},shader_cycles,{c_v:.0f}")
@@ -84,10 +90,11 @@ def main():
                 out.append(f"{k},mean_waves_per_simd,{vals[(k, 'SQ_WAVE_CYCLES')] * 4.0 / (1024.0 * cyc[(k, 'SQ_WAVE_CYCLES')]):.2f}")
         except KeyError:
             pass
-    if ("sr::k_mfcc", "SQ_INSTS_VALU") in vals:
-        out.append(f"sr::k_mfcc,valu_insts_per_frame,{vals[('sr::k_mfcc', 'SQ_INSTS_VALU')] / (65536 * 256.0):.1f}")
+    for km in ("sr::k_mfcc", "sr::k_mfcc_ext"):
+        if (km, "SQ_INSTS_VALU") in vals:
+            out.append(f"{km},valu_insts_per_frame,{vals[(km, 'SQ_INSTS_VALU')] / (batch * 256.0):.1f}")
     if ("sr::k_dtw_lds", "SQ_INSTS_VALU") in vals:
-        out.append(f"sr::k_dtw_lds,valu_insts_per_utt,{vals[('sr::k_dtw_lds', 'SQ_INSTS_VALU')] / 65536.0:.0f}")
+        out.append(f"sr::k_dtw_lds,valu_insts_per_utt,{vals[('sr::k_dtw_lds', 'SQ_INSTS_VALU')] / float(batch):.0f}")
     # HBM traffic of k_mfcc: FETCH_SIZE / WRITE_SIZE passes at the smaller batch encoded in the directory name; the
     # last k_mfcc launch of the run is bench.py's whole-batch pass (all tb utterances in one launch)
     tr = {}
@@ -97,7 +104,7 @@ def main():
         if not fs:
             continue
         for r in csv.DictReader(open(fs[0])):
-            if "sr::k_mfcc" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if "sr::k_mfcc" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE") and not desc:
                 tr[r["Counter_Name"]] = (float(r["Counter_Value"]), tb)
     if len(tr) == 2:
         (fs_, tb), (ws, _) = tr["FETCH_SIZE"], tr["WRITE_SIZE"]
@@ -118,7 +125,7 @@ def main():
             vj[k.split("::")[1] + "_valu_insts_per_utt"] = vals[(k, "SQ_INSTS_VALU")] / 65536.0
         if (k, "SQ_ACTIVE_INST_VALU") in vals:
             vj[k.split("::")[1] + "_valu_slots_per_utt"] = vals[(k, "SQ_ACTIVE_INST_VALU")] / 65536.0
-    if len(vj) > 3:
+    if len(vj) > 3 and not desc and batch == 65536:
         json.dump(vj, open(os.path.join(here, "pmc_valu.json"), "w"), indent=1)
     open(os.path.join(here, f"{tag}_rocprof_summary.csv"), "w").write("\n".join(out) + "\n")
     print("\n".join(out[-24:]))
