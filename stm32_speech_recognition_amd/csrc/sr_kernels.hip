@@ -1721,7 +1721,8 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         //   (x, y+1) inside    <=>  y1 <  ubA1                 (ubA1 = ub(x) + 1)
         //   (x+1, y) inside    <=>  lbB <  y1  &&  y1 <= ubB1  (ubB1 = ub(x+1) + 1)
         //   (x+1, y+1) inside  <=>  lbB <= y1  &&  y1 <  ubB1
-        auto ub1_of = [&](int xx) { return (xx < X1) ? 2 * xx + 2 : ((xx + c1s + 2) >> 1); };
+        const int c1s2 = c1s + 2;
+        auto ub1_of = [&](int xx) { return (xx < X1) ? 2 * xx + 2 : ((xx + c1s2) >> 1); };
         auto lb_of = [&](int xx) { return (xx < X2) ? (xx >> 1) : 2 * xx + c2s; };
         int xB = 2, y1 = 2;  // xB = x + 1, y1 = y + 1; DTW.C:147-148
         int ubA1 = ub1_of(1), lbB = lb_of(2), ubB1 = ub1_of(2);
@@ -1743,18 +1744,37 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             // down the literal three-root path.  The margin has to stay this tight: neighbouring frames are similar, so the
             // three candidates lie close together and a constant margin of 18 already put 4 % of the wave-steps on the
             // literal path (258: half of them).
-            const uint32_t q_up = in_up ? d_up : SR_DIS_ERR, q_rt = in_rt ? d_rt : SR_DIS_ERR, q_dg = in_dg ? d_dg : SR_DIS_ERR;
-            const uint32_t m2 = min(q_dg, min(q_rt, q_up));
+            // minimum over the admissible candidates: three v_min_u32 under the three admissibility masks (one v_mov + three
+            // v_min instead of three selects + two v_min; the masked-out candidates are never materialised)
+            const uint64_t m_up = __builtin_amdgcn_ballot_w64(y1 < ubA1),
+                           m_rt = __builtin_amdgcn_ballot_w64(lbB < y1) & __builtin_amdgcn_ballot_w64(y1 <= ubB1),
+                           m_dg = __builtin_amdgcn_ballot_w64(lbB <= y1) & __builtin_amdgcn_ballot_w64(y1 < ubB1);
+            uint32_t m2;
+            {
+                uint64_t ex;
+                asm volatile("v_mov_b32 %0, -1\n\t"
+                             "s_mov_b64 %1, exec\n\t"
+                             "s_and_b64 exec, %1, %2\n\t"
+                             "v_min_u32 %0, %0, %5\n\t"
+                             "s_and_b64 exec, %1, %3\n\t"
+                             "v_min_u32 %0, %0, %6\n\t"
+                             "s_and_b64 exec, %1, %4\n\t"
+                             "v_min_u32 %0, %0, %7\n\t"
+                             "s_mov_b64 exec, %1"
+                             : "=&v"(m2), "=&s"(ex)
+                             : "s"(m_dg), "s"(m_rt), "s"(m_up), "v"(d_dg), "v"(d_rt), "v"(d_up)
+                             : "scc");
+            }
             // the conditions that send the wave down the literal path are collected as LANE MASKS (ballots of the plain
             // compares, combined on the scalar unit): a bool OR-ed together and balloted afterwards costs two extra VALU ops
             const float s0 = __builtin_amdgcn_sqrtf((float)m2);
             uint32_t mn = (uint32_t)__int_as_float(__float_as_int(s0) + 1);  // floor(succ(s0)), see sqrt_floor_bracket
             const uint32_t mm = mn + 1, M = umul24(mm, mm), mg = (M >> 22) + 2, lo_t = sub_sat(M, mg), hi_t = M + mg;
-            const bool tie_dg = q_dg < lo_t, tie_up = q_up < lo_t;
+            const bool tie_dg = in_dg & (d_dg < lo_t), tie_up = in_up & (d_up < lo_t);
             const uint64_t unsafe = __builtin_amdgcn_ballot_w64(!(s0 > (float)mn)) | __builtin_amdgcn_ballot_w64(m2 >= 4294836225u) |
-                                    (~__builtin_amdgcn_ballot_w64(tie_dg) & __builtin_amdgcn_ballot_w64(q_dg < hi_t)) |
-                                    (~__builtin_amdgcn_ballot_w64(tie_up) & __builtin_amdgcn_ballot_w64(q_up < hi_t)) | lost;
-            bool mv_diag = tie_dg, mv_up = !tie_dg && tie_up;
+                                    (m_dg & ~__builtin_amdgcn_ballot_w64(d_dg < lo_t) & __builtin_amdgcn_ballot_w64(d_dg < hi_t)) |
+                                    (m_up & ~__builtin_amdgcn_ballot_w64(d_up < lo_t) & __builtin_amdgcn_ballot_w64(d_up < hi_t)) | lost;
+            bool mv_diag = tie_dg, mv_up = tie_up & !tie_dg;
             if (unsafe != 0ull) {  // wave-uniform; the literal form: dtw_limit on the three points, three roots, min, equality tests
                 const int x = xB - 1, y = y1 - 1;
                 in_up = !dtw_out(x, y1, X1, X2, (int)in_n, (int)mdl_n);
@@ -1781,7 +1801,10 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 lds_rows2(in_off, nrm_off, ci, ni);
                 asm volatile("v_mov_b32 %0, %1" : "+v"(ubA1) : "v"(ubB1));
                 {
-                    const int ua = 2 * xB + 2, ub = (xB + c1s + 2) >> 1, la = xB >> 1, lb = 2 * xB + c2s;
+                    int ua, lb;  // (xB << 1) + constant as ONE v_lshl_add_u32 each (the compiler shares 2*xB and spends two adds)
+                    asm("v_lshl_add_u32 %0, %1, 1, 2" : "=v"(ua) : "v"(xB));
+                    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(lb) : "v"(xB), "v"(c2s));
+                    const int ub = (xB + c1s2) >> 1, la = xB >> 1;
                     const uint64_t m1 = __builtin_amdgcn_ballot_w64(xB < X1), m2x = __builtin_amdgcn_ballot_w64(xB < X2);
                     asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(ubB1) : "v"(ub), "v"(ua), "s"(m1));
                     asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(lbB) : "v"(lb), "v"(la), "s"(m2x));
