@@ -422,7 +422,10 @@ constexpr int kMfccWaves = 4;       // waves per workgroup
 constexpr int kFramesPerWave = 16;   // consecutive frames one wave turns into MFCCs per work item
 constexpr int kFramesPerTile = kMfccWaves * kFramesPerWave;
 // per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
-constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMel + 64;  // the windowed frame aliases the exchange area;
+// rows of the filterbank outputs and of the DCT tables are kMelPad = 25 words apart: in the DCT the lanes of a wave read
+// 6 different frames x 12 different coefficients rows at the same column, and a stride of 24 folds those onto 4 banks
+constexpr int kMelPad = kMel + 1;
+constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMelPad + 64;  // the windowed frame aliases the exchange area;
                                                                         // the last 64 words hold the odd filters' lane offsets
 
 // (u32)(log((double)n)*100), MFCC.C:168, as a step function (see sr_tables.cpp gen_log_thr).
@@ -443,22 +446,22 @@ __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__res
 __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ uint32_t s_dctM[kCoef * kMel];
-    __shared__ int s_dctS[kCoef * kMel];  // 32-bit: read with the wide LDS loads, no byte extraction
+    __shared__ uint32_t s_dctM[kCoef * kMelPad];
+    __shared__ int s_dctS[kCoef * kMelPad];  // 32-bit: read with the wide LDS loads, no byte extraction
     __shared__ u32x4 s_tw3[8 * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
     uint16_t *xw = (uint16_t *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
-    uint32_t *powb = buf + kXchgWords, *moff = powb + kFramesPerWave * kMel;
+    uint32_t *powb = buf + kXchgWords, *moff = powb + kFramesPerWave * kMelPad;
 
     // DCT term (MFCC.C:179): (s32)pow * dct / 100, truncated toward zero, with 0 <= pow <= 2218 (= (u32)(ln(2^32)*100))
     // and |dct| <= 128.  floor(pow*|c|/100) == (pow * M_c) >> 18 with M_c = ceil(|c| * 2^18 / 100) for every such pair
     // (the rounding excess pow*eps/2^18 stays below 1/100 because 100*pow < 2^18); the log stage stores pow << 14 so
     // the quotient is one v_mul_hi_u32, and the sign of c is applied by the accumulating 24-bit multiply.
     for (int i = threadIdx.x; i < kCoef * kMel; i += blockDim.x) {
-        const int c = a.t.dct[i];
-        s_dctM[i] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
-        s_dctS[i] = (c > 0) - (c < 0);
+        const int c = a.t.dct[i], o = (i / kMel) * kMelPad + i % kMel;
+        s_dctM[o] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
+        s_dctS[o] = (c > 0) - (c < 0);
     }
     __syncthreads();
 
@@ -605,20 +608,21 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 const uint32_t *P = buf + ((lane & 1) ? kBins : 0), *X = (lane & 1) ? moff : buf + 2 * kBins;
                 const int ih = f_hi - 1, il = f_lo - 1;
                 const uint32_t hi = P[ih] + X[ih >> 3], lo = f_lo ? P[il] + X[il >> 3] : 0u;
-                powb[fi * kMel + lane] = hi - lo;
+                powb[fi * kMelPad + lane] = hi - lo;
             }
             wave_sync();
         }
 
         // ---- log (MFCC.C:165-170) and DCT (MFCC.C:173-183) for the wave's nf frames, all lanes busy
-        for (uint32_t t = lane; t < nf * kMel; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
+        // (the pad word of each row goes through the log as well: harmless, never read)
+        for (uint32_t t = lane; t < nf * kMelPad; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
         wave_sync();
         for (uint32_t t = lane; t < nf * kCoef; t += 64) {
             const uint32_t fi = t / kCoef, h = t - fi * kCoef;
             int acc = 0;
 #pragma unroll
             for (int i = 0; i < kMel; i++)
-                acc = mad24((int)__umulhi(powb[fi * kMel + i], s_dctM[h * kMel + i]), s_dctS[h * kMel + i], acc);
+                acc = mad24((int)__umulhi(powb[fi * kMelPad + i], s_dctM[h * kMelPad + i]), s_dctS[h * kMelPad + i], acc);
             out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
         }
         wave_sync();
@@ -655,7 +659,8 @@ constexpr int kXStride = 65;                  // exchange image: element e of la
 constexpr int kXSub = 16 * kXStride;          // one sub-transform
 constexpr int kXWords = 2 * kXSub;            // 2080; later reused for energies and prefix sums
 constexpr int kEStride = 336;                 // energies of one frame: bin k at k + 4*(k >> 4), frames 336 words apart
-constexpr int kWaveWords = kXWords + 2 * 16 * kGrp + kFpw * kMelE;  // + prefix lane offsets + filterbank outputs
+constexpr int kMelEPad = kMelE + 1;             // row stride of the filterbank outputs / DCT tables (see kMelPad)
+constexpr int kWaveWords = kXWords + 2 * 16 * kGrp + kFpw * kMelEPad;  // + prefix lane offsets + filterbank outputs
 static_assert(kFL == 2 * 16 * 10, "a 16-lane frame group windows 10 sample pairs per lane");
 static_assert(kGrp * kEStride <= kXWords && kGrp * 2 * kBinsE <= kXWords, "energies / prefix sums reuse the exchange image");
 }  // namespace ext
@@ -674,17 +679,17 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
 {
     using namespace ext;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ uint32_t s_dctM[kCoef * kMelE];  // same exact-division-by-100 device as k_mfcc (see there)
-    __shared__ int s_dctS[kCoef * kMelE];
+    __shared__ uint32_t s_dctM[kCoef * kMelEPad];  // same exact-division-by-100 device as k_mfcc (see there)
+    __shared__ int s_dctS[kCoef * kMelEPad];
     __shared__ u32x4 s_tw4[8 * 16], s_w512[8 * 16], s_tri[8 * 16];  // per-lane constants of layout B, chunk c of lane l at [c*16 + l]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, gl = lane & 15;
     uint32_t *xb = smem + w * kWaveWords;
     uint32_t *moff = xb + kXWords, *powb = moff + 2 * 16 * kGrp;
     for (int i = threadIdx.x; i < kCoef * kMelE; i += blockDim.x) {
-        const int c = a.t.dct[i];
-        s_dctM[i] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
-        s_dctS[i] = (c > 0) - (c < 0);
+        const int c = a.t.dct[i], o = (i / kMelE) * kMelEPad + i % kMelE;
+        s_dctM[o] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
+        s_dctS[o] = (c > 0) - (c < 0);
     }
     // ---- constants of layout A: lane = (d2, d3) --------------------------------------------------
     const int base = rev2(gl >> 2) + 4 * rev2(gl & 3);
@@ -911,19 +916,19 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
                     const uint32_t *P = xb + g * 512 + ((h & 1) ? 256 : 0), *X = moff + g * 32 + ((h & 1) ? 16 : 0);
                     const int ih = f_hi[q] - 1, il = f_lo[q] - 1;
                     const uint32_t hi = P[ih] + X[ih >> 4], lo = f_lo[q] ? P[il] + X[il >> 4] : 0u;
-                    if (live) powb[fi * kMelE + h] = hi - lo;
+                    if (live) powb[fi * kMelEPad + h] = hi - lo;
                 }
             }
             wave_sync();
         }
-        for (uint32_t t = lane; t < nf * kMelE; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
+        for (uint32_t t = lane; t < nf * kMelEPad; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
         wave_sync();
         for (uint32_t t = lane; t < nf * kCoef; t += 64) {
             const uint32_t fi = t / kCoef, h = t - fi * kCoef;
             int acc = 0;
 #pragma unroll
             for (int i = 0; i < kMelE; i++)
-                acc = mad24((int)__umulhi(powb[fi * kMelE + i], s_dctM[h * kMelE + i]), s_dctS[h * kMelE + i], acc);
+                acc = mad24((int)__umulhi(powb[fi * kMelEPad + i], s_dctM[h * kMelEPad + i]), s_dctS[h * kMelEPad + i], acc);
             out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
         }
         wave_sync();
