@@ -237,7 +237,16 @@ int sr_create(const sr_config *cfg, sr_engine **out)
         h->pipe_max_chunks = env_u32("SR_PIPE_MAX_CHUNKS", 12, 1, 64);
     }
     h->mfcc_tile = mfcc_frames_per_tile(h->frame_len);
-    h->mfcc_grid_cap = mfcc_resident_workgroups(h->frame_len);
+    // Grid of the frame kernel: FOUR times the workgroups that are resident at once, work items strided.  Exactly the
+    // resident set (one persistent wave of workgroups) left ~15 % of the kernel's own time to stragglers: the workgroups
+    // do not finish together, and with more, shorter ones the dispatcher back-fills the CUs that are done (measured alone
+    // on the chip, 65 536 x 256 frames: 1024 workgroups 19.0 ms, 2048 17.8, 4096 17.1, 16 384 16.6; the per-workgroup
+    // set-up -- coefficient and DCT tables -- is amortised over 80 items at 4096).
+    h->mfcc_grid_cap = 4 * mfcc_resident_workgroups(h->frame_len);
+    if (const char *gv = getenv("SR_MFCC_GRID")) {  // tuning override: workgroups of the frame kernel
+        const long x = atol(gv);
+        if (x > 0) h->mfcc_grid_cap = (uint32_t)x;
+    }
     build_tables(h->host, fe);
     // one blob, 16-byte aligned sub-tables
     const HostTables &t = h->host;

@@ -964,8 +964,8 @@ uint32_t mfcc_resident_workgroups(uint32_t frame_len)
 void launch_mfcc(const MfccArgs &a, hipStream_t s)
 {
     if (a.n_items == 0) return;
-    // persistent-style grid: exactly the workgroups that are resident at once, work items strided
-    const uint32_t cap = a.grid_cap ? a.grid_cap : 1024u;
+    // persistent-style grid: a few times the workgroups that are resident at once (see sr_create), work items strided
+    const uint32_t cap = a.grid_cap ? a.grid_cap : 4096u;
     const uint32_t grid = a.n_items < cap ? a.n_items : cap;
     if (a.frame_len == 320) {
         const size_t lds = (size_t)ext::kWaves * ext::kWaveWords * sizeof(uint32_t);
