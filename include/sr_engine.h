@@ -46,7 +46,11 @@ extern "C" {
 #define SR_DIS_ERR 0xFFFFFFFFu /* dis_err / dis_max, DTW.H:4-5 */
 #define SR_SAVE_MASK 12345u    /* save_mask, Flash.H:11 */
 
-/* ------------------------------------------------------------------ configuration */
+/* ------------------------------------------------------------------ configuration
+ * The kernels are built for TWO front ends and sr_create accepts exactly those (SR_ERR_BAD_CONFIG otherwise):
+ *   reference   fs 8000, 20/10 ms framing (160/80 samples), nfft 1024, 24 Mel, 12 MFCC   (ADC.H, VAD.H, MFCC.H)
+ *   extension   fs 16000, 20/10 ms framing (320/160 samples), nfft 512, 40 Mel, 12 MFCC   (no reference counterpart)
+ * What is free at run time: max_frames (2..16383), noise_len_ms (a multiple of 60), max_seg (1..3), device. */
 typedef struct sr_config {
     uint32_t fs;            /* ADC.H:7       8000 */
     uint32_t frame_time_ms; /* VAD.H:5       20  -> frame_len 160 */

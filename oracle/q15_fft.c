@@ -25,7 +25,7 @@
  * truncation error of the five >>2 passes.
  *
  * The coefficient table is regenerated from its closed form rather than
- * pasted; tests/test_oracle_tables.py parses the table out of the .s file
+ * pasted; tests/test_oracle.py::test_twiddles_regenerate_asm_table parses the table out of the .s file
  * (when /root/reference is present) and requires 0 mismatches.
  */
 #include <math.h>

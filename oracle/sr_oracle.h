@@ -6,15 +6,17 @@
  *   noise_atap -> VAD -> get_mfcc (fft -> cr4_fft_1024_stm32) -> dtw -> spch_recg
  * (reference Src/Speech_Recog/{VAD,MFCC,DTW}.C, Src/BSP/cr4_fft_1024_stm32.s,
  * Src/APP/main.c:249-296).  At the reference's compile-time constants it is
- * required (tests/test_oracle_vs_ref.py) to be bit-identical to tier (i) =
+ * required (tests/test_oracle.py, tests/test_real_audio.py) to be bit-identical to tier (i) =
  * oracle/_ref/libsr_ref.so, the reference's own .C files compiled verbatim.
  * It exists because the reference's #defines are unguarded, so the verbatim
  * build cannot run the 256-frame / many-template benchmark shapes.
  *
  * Parity pinning: the reference ships NO golden vectors or tests (SURVEY.md
- * section 4).  Parity is pinned by tier (i) run in the build container, and by
- * fixtures under tests/golden/ generated from tier (i) by
- * tests/golden/make_golden.py.
+ * section 4).  Parity is pinned by tier (i) run in the build container -- at the
+ * reference's constants (119 frames) and, through oracle/_ref/libsr_ref320.so
+ * (the same .C files with vv_tim_max raised, see oracle/Makefile), at the
+ * benchmark's 256-frame / 100-template shape -- and by fixtures under
+ * tests/golden/ generated from tier (i) by tests/golden/make_golden.py.
  */
 #ifndef SR_ORACLE_H
 #define SR_ORACLE_H
