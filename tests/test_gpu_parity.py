@@ -594,6 +594,44 @@ def test_delta_mfcc_extension_matches_its_oracle(eng119, oracle, golden):
         assert not got[b, n:].any()
 
 
+def test_template_store_swap_while_work_is_in_flight(golden):
+    """sr_set_templates right behind an asynchronous sr_recognize_batch_dev on a side stream: the call waits for the
+    device before it touches the store (the kernels in flight keep reading the old rows), publishes the new store
+    atomically, and a failing upload leaves the previous store in place."""
+    from stm32_speech_recognition_amd.engine import Engine, SrError, results_from_torch
+    dev = torch.device("cuda", 0)
+    eng = Engine(device=0)
+    store_a = golden["store"].copy()
+    store_b = golden["store"].copy()
+    nslots = len(store_b) // 4096
+    store_b = np.roll(store_b.reshape(nslots, 4096), 3, axis=0).reshape(-1).copy()      # same models, other slots
+    pcm = torch.from_numpy(np.tile(golden["pcm"], (64, 1)).view(np.int16)).to(dev)       # enough work to still be running
+    B = pcm.shape[0]
+    eng.set_templates_store(store_a)
+    ref_a = eng.recognize(golden["pcm"], want_mfcc=False, want_vad=False)
+    out = eng.alloc_outputs(B, dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    eng.recognize_dev(pcm, out, stream=side.cuda_stream)
+    eng.set_templates_store(store_b)                                                     # must not disturb the launch above
+    ref_b = eng.recognize(golden["pcm"], want_mfcc=False, want_vad=False)
+    torch.cuda.synchronize()
+    n = len(golden["pcm"])
+    got = out["scores"].cpu().numpy().view(np.uint32)
+    for rep in (0, 17, 63):
+        assert np.array_equal(got[rep * n:(rep + 1) * n], ref_a["scores"]), rep
+    assert np.array_equal(np.roll(ref_a["scores"], 3, axis=1), ref_b["scores"])
+    res = results_from_torch(out["results"])
+    assert np.array_equal(res["min_dis"][:n], ref_a["results"]["min_dis"])
+    with pytest.raises(SrError):                                                         # slot claims more frames than fit
+        bad = store_b.copy()
+        bad[:4].view(np.uint16)[:] = (12345, 4000)
+        eng.set_templates_store(bad)
+    again = eng.recognize(golden["pcm"], want_mfcc=False, want_vad=False)
+    assert np.array_equal(again["scores"], ref_b["scores"])
+    eng.close()
+
+
 # ----------------------------------------------------------------------------- multi-GPU surface of the C ABI
 def _multi_case(devices, golden):
     """sr_multi_* on `devices`: sharded recognition + RCCL all-gather == the single-engine answer, host and device API"""
