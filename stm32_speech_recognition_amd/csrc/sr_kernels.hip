@@ -1132,6 +1132,8 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
         z_thl = (uint32_t)kFrameLen * 2 / 160 / 1;       // VAD.C:70
     }
     const uint32_t a_thl = mid + n_thl, b_thl = mid - n_thl;  // VAD.C:112-113 (u32, may wrap)
+    const uint32_t mid2 = (mid & 0xFFFFu) * 0x10001u;          // mid in both halves
+    const bool mid16 = mid <= 0xFFFFu;                         // wave-uniform
 
     // ---- per-frame short-time magnitude and band-crossing count (VAD.C:121-157) ----------------
     // Frames start every 80 samples, so both quantities are assembled from per-80-sample block
@@ -1161,11 +1163,19 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
             for (int t = 0; t < kHop / 8; t++) {
                 const uint4 q = row[(uint64_t)j * (kHop / 8) + t];
                 const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+                // sum |x - mid| of two samples per instruction (v_sad_u16: |a.lo-b.lo| + |a.hi-b.hi| + c).  mid is a mean of
+                // u16 samples (VAD.C:41-47); thresholds handed in by a caller may hold anything, then the plain form runs
+                if (mid16) {
+#pragma unroll
+                    for (int wdi = 0; wdi < 4; wdi++) A = __builtin_amdgcn_sad_u16(wds[wdi], mid2, A);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 8; s++) A += absdiff((wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF, mid);
+                }
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
                     const int off = t * 8 + s;
                     const uint32_t x = (wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF;
-                    A += absdiff(x, mid);
                     const uint32_t c = (x >= a_thl) ? 2u : (x < b_thl ? 1u : 0u);
                     if (off == kHop - 1) c78 = last;
                     const bool nz = c != 0;

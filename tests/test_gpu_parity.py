@@ -530,6 +530,29 @@ def test_compat_symbols_match_golden(golden, oracle):
     assert label is None and dis == compat.DIS_ERR  # main.c:261-266
 
 
+def test_compat_vad_with_caller_thresholds_outside_the_sample_range(golden, oracle):
+    """VAD() takes its thresholds from the caller (VAD.C:97); a mid value that is not a 16-bit quantity -- nothing
+    noise_atap could produce -- must still follow the reference's u32 arithmetic (the kernel's two-samples-per-instruction
+    |x - mid| path only covers 16-bit mids)."""
+    from stm32_speech_recognition_amd import compat
+    pcm = golden["pcm"][2]
+    x = pcm.astype(np.int64)
+    fsum = lambda mid: np.array([np.abs(x[80 * f:80 * f + 160] - mid).sum() for f in range((16000 - 160) // 80)])
+    n_found = 0
+    for mid, n_thl, z_thl, pct in ((70000, 20, 2000, 0.3), (70000, 20, 2000, 0.55), (65536, 3, 2000, 0.55), (65535, 40, 2000, 0.3),
+                                   (100000, 5, 2000, 0.55), (0, 2100, 2, 0.55)):
+        fs = fsum(mid)
+        s_thl = int(np.sort(fs)[int(len(fs) * pct)])            # a good share of the frames is "loud" by a hair: every sum counts
+        at = compat.atap_tag(mid, n_thl, z_thl, s_thl)
+        oa = ol.Atap(mid, n_thl, z_thl, s_thl)
+        want = oracle.vad(pcm, oa)
+        got = compat.VAD(pcm, compat.VCBUF_LEN, at)
+        for i in range(3):
+            assert got[i] == (None if want[2 * i] < 0 else want[2 * i], None if want[2 * i + 1] < 0 else want[2 * i + 1]), (mid, i)
+        n_found += sum(1 for i in range(3) if want[2 * i] >= 0)
+    assert n_found >= 5                                          # the cases are not all "no segment"
+
+
 def test_compat_dtw_slot_scan_uploads_each_model_once(golden):
     """The firmware's slot scan (main.c:279-291: one dtw() per flash slot and utterance) through the scalar symbol:
     a model is uploaded the first time it is seen and one launch scores an input record against every cached model,
