@@ -298,7 +298,7 @@ class RefLib:
 class RefLib320(RefLib):
     """Tier (i) at vv_frm_max = 320: the reference's VAD.C / MFCC.C / DTW.C compiled from where they lie with one
     compile-time constant changed (vv_tim_max 1200 -> 3210 ms, MFCC.H:15, through a sed-patched temporary copy of that
-    header in the git-ignored build directory; see oracle/Makefile)."""
+    header in a temporary build directory outside the repository; see oracle/Makefile)."""
     FTR_BYTES = 4 + 320 * 12 * 2
     FRM_MAX = 320
     PATH = REF320_PATH

@@ -364,7 +364,7 @@ def test_tier2_equals_reference_objects_at_benchmark_shape():
     """BASELINE configs[2]'s shape (256-frame utterances, 100 templates of 192..320 frames) through the REFERENCE'S OWN
     compiled VAD.C / MFCC.C / DTW.C: the objects are built with vv_tim_max = 3210 ms instead of 1200 (the one constant
     that caps a record at 119 frames, MFCC.H:15-16; oracle/Makefile writes a patched temporary copy of that header into
-    the git-ignored build directory).  The parametrised restatement (tier ii), which is the oracle of every 256-frame
+    a temporary build directory outside the repository).  The parametrised restatement (tier ii), the oracle of every 256-frame
     GPU test and of bench.py, has to agree with them bit for bit: thresholds, segments, every MFCC vector, all 100
     scores, the argmin -- the same generator and seeds as bench.py."""
     r = ol.RefLib320()
