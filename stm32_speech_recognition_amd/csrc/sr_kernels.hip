@@ -1083,7 +1083,10 @@ constexpr int kVadWaves = 4;
 
 __device__ __forceinline__ uint32_t absdiff(uint32_t v, uint32_t mid) { return v > mid ? v - mid : mid - v; }
 
-template <int kFrameLen, int kHop>  // 160/80 = the reference (VAD.H:5-8); 320/160 = the 16 kHz extension
+// kSad: |x - mid| sums of two samples per instruction (v_sad_u16).  Only valid for 16-bit mid values, which is what
+// noise_atap produces (a mean of u16 samples, VAD.C:41-47); the variant without it serves callers that hand their own
+// thresholds in (atap_in), which may hold anything.
+template <int kFrameLen, int kHop, bool kSad>  // 160/80 = the reference (VAD.H:5-8); 320/160 = the 16 kHz extension
 __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -1132,8 +1135,7 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
         z_thl = (uint32_t)kFrameLen * 2 / 160 / 1;       // VAD.C:70
     }
     const uint32_t a_thl = mid + n_thl, b_thl = mid - n_thl;  // VAD.C:112-113 (u32, may wrap)
-    const uint32_t mid2 = (mid & 0xFFFFu) * 0x10001u;          // mid in both halves
-    const bool mid16 = mid <= 0xFFFFu;                         // wave-uniform
+    const uint32_t mid2 = (mid & 0xFFFFu) * 0x10001u;          // mid in both halves (kSad)
 
     // ---- per-frame short-time magnitude and band-crossing count (VAD.C:121-157) ----------------
     // Frames start every 80 samples, so both quantities are assembled from per-80-sample block
@@ -1163,9 +1165,7 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
             for (int t = 0; t < kHop / 8; t++) {
                 const uint4 q = row[(uint64_t)j * (kHop / 8) + t];
                 const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-                // sum |x - mid| of two samples per instruction (v_sad_u16: |a.lo-b.lo| + |a.hi-b.hi| + c).  mid is a mean of
-                // u16 samples (VAD.C:41-47); thresholds handed in by a caller may hold anything, then the plain form runs
-                if (mid16) {
+                if (kSad) {  // v_sad_u16: |a.lo-b.lo| + |a.hi-b.hi| + c
 #pragma unroll
                     for (int wdi = 0; wdi < 4; wdi++) A = __builtin_amdgcn_sad_u16(wds[wdi], mid2, A);
                 } else {
@@ -1349,10 +1349,14 @@ void launch_vad(const VadArgs &a, hipStream_t s)
 {
     if (!a.B) return;
     const dim3 grid((a.B + kVadWaves - 1) / kVadWaves), block(64 * kVadWaves);
-    if (a.frame_len == 320)
-        hipLaunchKernelGGL((k_vad<320, 160>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((k_vad<160, 80>), grid, block, 0, s, a);
+    const bool own_thresholds = a.atap_in == nullptr;  // noise_atap runs in the kernel: mid is a 16-bit quantity
+    if (a.frame_len == 320) {
+        if (own_thresholds) hipLaunchKernelGGL((k_vad<320, 160, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_vad<320, 160, false>), grid, block, 0, s, a);
+    } else {
+        if (own_thresholds) hipLaunchKernelGGL((k_vad<160, 80, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_vad<160, 80, false>), grid, block, 0, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
