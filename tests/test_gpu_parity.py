@@ -844,6 +844,48 @@ def test_extension_front_end_matches_its_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("seed,maxf", [(1, 150), (2, 64), (3, 333)])
+def test_extension_front_end_ragged_lengths(seed, maxf):
+    """EXTENSION front end on ragged batches: frame counts from 1 to beyond the cap (k_mfcc_ext works on four frames at a
+    time and reads the next batch ahead: partial groups, waves without frames, runs of empty work items, frame caps that
+    are not a multiple of the 32-frame tile), silent captures in between; MFCC, scores and argmin against the oracle."""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(700 + seed)
+    cfg = dict(fs=16000, nfft=512, n_mel=40)
+    K, B = 9, 90
+    orc = ol.Oracle(max_frames=maxf, **cfg)
+    bank = synth.word_bank(6)
+    tmax = min(maxf, 140)
+    tfr = [int(v) for v in rng.integers(max(8, tmax // 2), tmax + 1, K)]
+    S = synth.buf_len_for(int(tmax * 1.25) + 4, 2)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(K) % 6, tfr, seed=31 + seed, bank=bank, rate=2, S=S))
+    tm = np.zeros((K, maxf + 1, 12), np.int16)
+    for k in range(K):
+        rc, a = orc.noise_atap(tp[k])
+        seg = orc.vad(tp[k], a)
+        n, m = orc.mfcc(tp[k], seg[0], seg[1], a)
+        assert n == tfr[k]
+        tm[k, :n] = m
+    tf = np.array(tfr, np.uint32)
+    frames = [int(v) for v in rng.integers(8, int(tmax * 1.25) + 1, B)]          # some beyond the cap -> MFCC fail
+    frames[:12] = [8, 9, 10, 11, 12, 13, 31, 32, 33, 63, 64, 65]
+    pcm = synth.as_u16_numpy(synth.make_utterances(rng.integers(0, 6, B), frames, seed=41 + seed, bank=bank, rate=2, S=S))
+    for b in (14, 15, 16, 40):
+        pcm[b] = 2048 + b % 2                                                      # runs of captures without frames
+    eng = Engine(max_frames=maxf, device=0, **cfg)
+    eng.set_templates_dense(tm, tf)
+    out = eng.recognize(pcm)
+    tpl = orc.make_templates(tm, tf)
+    ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
+    assert np.array_equal(out["results"]["status"], ores["status"]) and np.array_equal(out["results"]["frm_num"], ores["frm_num"])
+    assert len(set(ores["frm_num"].tolist())) > 20 and ((ores["status"] == ol.ST_MFCC_FAIL).any() or int(tmax * 1.25) <= maxf)
+    assert np.array_equal(out["mfcc"], omf)
+    assert np.array_equal(out["scores"], osc)
+    for f in ("best_tpl", "min_dis"):
+        assert np.array_equal(out["results"][f], ores[f]), f
+    eng.close()
+
+
 def test_dtw_generic_fallback_matches_oracle():
     """sequences too long for the LDS-staged kernel (max_frames = 6000) and more than 1024 templates go through
     the generic global-memory walk k_dtw: same arithmetic, must give the same scores"""
