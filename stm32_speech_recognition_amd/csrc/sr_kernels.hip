@@ -108,7 +108,10 @@ __device__ __forceinline__ uint32_t pk_hi16(int lo_src, int hi_src)
 __device__ __forceinline__ uint32_t pk_s15(int lo_src, int hi_src)
 {
     uint32_t r = (uint32_t)lo_src >> 15;
-    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+    // trailing s_nop 0: a VALU read of a register right after a partial (dst_sel != DWORD) SDWA write of it needs one wait
+    // state on gfx940-class chips (LLVM's "dst_sel forwarding hazard"); the compiler inserts it for its own SDWA code but
+    // cannot see into the asm
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\ts_nop 0"
         : "+v"(r)
         : "v"(15), "v"(hi_src));
     return r;
@@ -161,8 +164,12 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
     v += dpp_take<0x112, 0xF>(v);  // row_shr:2
     v += dpp_take<0x114, 0xF>(v);  // row_shr:4
     v += dpp_take<0x118, 0xF>(v);  // row_shr:8
-    v += dpp_take<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-    v += dpp_take<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3, accumulated IN PLACE: lanes of the rows the mask
+    // disables keep their value, which is what the sum needs there (through the intrinsic the compiler spends a v_mov and a
+    // v_mov_dpp on the "old" value of the disabled rows)
+    // (s_nop 1: a DPP read needs two wait states after the VALU write of its source; the compiler cannot see into the asm)
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v));
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v));
     return v;
 }
 
@@ -1825,7 +1832,9 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(lb) : "v"(xB), "v"(c2s));
                     const int ub = (xB + c1s2) >> 1, la = xB >> 1;
                     const uint64_t m1 = __builtin_amdgcn_ballot_w64(xB < X1), m2x = __builtin_amdgcn_ballot_w64(xB < X2);
-                    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(ubB1) : "v"(ub), "v"(ua), "s"(m1));
+                    // s_nop 1: the masks come straight from v_cmp, and a VALU read of an SGPR written by the VALU needs two
+                    // wait states (the compiler pads its own v_cmp -> v_cndmask pairs the same way)
+                    asm volatile("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(ubB1) : "v"(ub), "v"(ua), "s"(m1));
                     asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(lbB) : "v"(lb), "v"(la), "s"(m2x));
                 }
             }
