@@ -233,7 +233,8 @@ int sr_allgather_scores(void *nccl_comm, const uint32_t *d_scores, uint32_t *d_a
  * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 2048 utterances each, at most
  * SR_PIPE_MAX_CHUNKS = 12) and runs them on SR_PIPE_STREAMS = 3 (max 4) internal streams forked from / joined to the
  * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap (environment
- * variables read by sr_create; SR_PIPE_STREAMS=1 keeps everything on the caller's stream).
+ * variables read by sr_create; SR_PIPE_STREAMS=1 keeps everything on the caller's stream).  SR_MFCC_GRID overrides the
+ * number of workgroups of the frame kernel (default: four times the workgroups resident at once).
  * With profiling on, every kernel launch is bracketed with hipEvents on the stream it is launched on;
  * sr_get_stage_ms synchronises and returns, averaged over everything recorded since sr_set_profiling(h, 1):
  * ms[0] VAD, ms[1] MFCC (frame kernel), ms[2] DTW, ms[3] argmin = duration of ONE launch of that kernel (under

@@ -15,7 +15,9 @@ def env_rank():
 def init_process_group(backend, local_rank=0):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+    # the host driver of these boxes only supports dmabuf IPC: without this RCCL / cross-process tensor sharing fails with
+    # "hipIpcGetMemHandle: invalid argument" (stated for this image; already exported in its environment, kept as a default)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -43,7 +45,7 @@ def all_gather_scores(local_scores, world, out=None):
 
 class ScoreExchange:
     """Double-buffered exchange step: the all-gather of step i's scores runs on the collective's own stream while
-    the kernels of step i+1 fill the other buffer (the collective is ~1 ms of xGMI traffic next to ~33 ms of
+    the kernels of step i+1 fill the other buffer (the collective is ~1 ms of xGMI traffic next to ~24 ms of
     kernels, but serialising it would still cost a few percent of scaling efficiency).
 
         x = ScoreExchange(world, [gathered0, gathered1])
