@@ -1,8 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- utterances/s of the isolated-word recognition hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (plain command at every N: for N > 1 it launches its own ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+N > 1 without a launcher (WORLD_SIZE unset): `--launcher ranks` (default) starts N copies of this script, one rank per
+GPU over RCCL (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set here, free port on 127.0.0.1), forwards rank 0's JSON line
+as the only stdout line and returns the first non-zero exit code; `--launcher single` runs ONE process that drives the
+N GPUs through the C ABI's sr_multi_* surface (csrc/sr_multi.cpp: one engine per device, one grouped in-place
+ncclAllGather per step).  Under torch.distributed.run (WORLD_SIZE set) the script is one rank, as before.
 
 A "step" = one pass of the whole hot path (noise_atap -> VAD -> MFCC -> greedy DTW x K templates ->
 argmin) over one batch of synthetic capture buffers that is already resident in HBM.
@@ -12,10 +18,14 @@ over ranks, templates replicated, and each step ends with one RCCL all-gather of
 matrix (N > 1 only; double-buffered so that it overlaps the next step's kernels).  Inside a step the engine cuts the
 batch into chunks on three internal streams.  Prints ONE JSON line on rank 0.
 `--batch 4096 --templates 10` is BASELINE configs[1] (a parity-test shape, not the headline metric).
+At N = 1 the default run also times BASELINE configs[1] and configs[4] (the extension front end, no reference
+counterpart) for a few steps each and reports them under `other_configs` -- never in `value`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,8 +40,8 @@ from stm32_speech_recognition_amd import dist_util as du  # noqa: E402
 from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch  # noqa: E402
 
 T = 256            # frames per utterance (metric: "256-frame, 100 templates")
-K = 100            # templates
-N_WORDS = 20       # vocabulary the templates are spoken from (comm_num, Flash.H:17)
+K_DEFAULT = 100    # templates
+N_WORDS_DEFAULT = 20  # vocabulary the templates are spoken from (comm_num, Flash.H:17)
 MAX_FRAMES = 320   # frame cap: templates run 192..320 frames
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -46,7 +56,7 @@ def mfcc_kernel_bytes_per_utt(T, C):
     return 2 * (80 * (T - 1) + 160 + 1) + 2 * T * C + 48
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -58,56 +68,119 @@ def main():
     ap.add_argument("--workload", choices=["ref", "ext"], default="ref",
                     help="ref = BASELINE configs[2] (the metric's config); ext = configs[4], the 16 kHz/512-pt/40-Mel x 500 "
                          "templates EXTENSION (no reference counterpart; not the headline metric)")
-    args = ap.parse_args()
-    global K, N_WORDS
-    rate, eng_cfg = 1, {}
-    if args.workload == "ext":
-        rate, eng_cfg, K, N_WORDS = 2, dict(fs=16000, nfft=512, n_mel=40), 500, 100
-    if args.templates:
-        K = args.templates
-        N_WORDS = min(N_WORDS, K)
+    ap.add_argument("--launcher", choices=["ranks", "single"], default="ranks",
+                    help="N > 1 started as a plain command: ranks = one process per GPU over torch.distributed/RCCL "
+                         "(started by this script); single = one process, sr_multi_* C ABI")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra N = 1 measurements of configs[1] and configs[4] (other_configs)")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each other_configs entry")
+    ap.add_argument("--other-scale", type=int, default=1,
+                    help="tests: divide the other_configs batches by this and run them whatever the headline shape is")
+    return ap.parse_args(argv)
 
-    rank, local_rank, world = du.env_rank()
-    # test hooks (tests/test_gpu_parity.py runs the N = 2 code path on a 1-GPU box): collective backend and a forced
-    # device ordinal.  The driver never sets them: N > 1 means one rank per GPU over RCCL.
-    backend = os.environ.get("SR_BENCH_BACKEND", "nccl")
-    if "SR_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["SR_BENCH_DEVICE"])
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        du.init_process_group(backend, local_rank)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    B = args.batch
-    S = synth.buf_len_for(T, rate)
 
-    eng = Engine(max_frames=MAX_FRAMES, device=local_rank, **eng_cfg)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    # ---- templates: K synthetic words through the SAME front end (main.c:121-138 save_mdl) ----------
-    bank = synth.word_bank(N_WORDS)
+
+def self_launch(args):
+    """`python bench.py --gpus N` as a plain command: start the N ranks ourselves (what torch.distributed.run would do:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, one process per GPU) and forward rank
+    0's JSON line as the only line on stdout.  Everything else the ranks print goes to stderr.  The first rank that fails
+    ends the job: the others are terminated (by PID) and its exit code is returned."""
+    n = args.gpus
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SR_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    import threading
+    lines = []
+
+    def pump():
+        for ln in procs[0].stdout:
+            if ln.startswith("{"):
+                lines.append(ln)
+            else:
+                sys.stderr.write(ln)
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc = 0
+    alive = set(range(n))
+    while alive and rc == 0:
+        for r in list(alive):
+            c = procs[r].poll()
+            if c is not None:
+                alive.discard(r)
+                if c != 0:
+                    rc = c
+                    sys.stderr.write(f"bench.py: rank {r} exited with code {c}; stopping the other ranks\n")
+        time.sleep(0.05)
+    for r in alive:  # only after a failure
+        procs[r].terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    th.join(timeout=10)
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n")
+        rc = 1
+    if rc == 0:
+        j = json.loads(lines[0])
+        j["launcher"] = "ranks (started by bench.py itself: one process per GPU over torch.distributed)"
+        print(json.dumps(j), flush=True)
+    return rc
+
+
+def workload_setup(args, workload, Kt):
+    """front-end configuration of a workload: (rate, engine config keywords, templates, vocabulary size)"""
+    if workload == "ext":
+        return 2, dict(fs=16000, nfft=512, n_mel=40), Kt or 500, min(100, Kt or 500)
+    return 1, {}, Kt or K_DEFAULT, min(N_WORDS_DEFAULT, Kt or K_DEFAULT)
+
+
+def make_templates(eng, bank, Kt, n_words, rate, dev):
+    """Kt synthetic words through the SAME front end (main.c:121-138 save_mdl) -> dense template set on the host"""
     rng = np.random.default_rng(2026)
-    tfr = rng.integers(192, 321, K)
-    tpcm = synth.make_utterances(np.arange(K) % N_WORDS, tfr, seed=77, bank=bank, S=synth.buf_len_for(320, rate), device=dev,
+    tfr = rng.integers(192, 321, Kt)
+    tpcm = synth.make_utterances(np.arange(Kt) % n_words, tfr, seed=77, bank=bank, S=synth.buf_len_for(320, rate), device=dev,
                                  rate=rate)
     tvad, tmf = eng.features_dev(tpcm)
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     tv = vad_from_torch(tvad)
     assert (tv["status"] == 0).all() and np.array_equal(tv["frm_num"], tfr), "template front end did not yield the planned frame counts"
-    tm = np.concatenate([tmf.cpu().numpy(), np.zeros((K, 1, 12), np.int16)], 1)
+    tm = np.concatenate([tmf.cpu().numpy(), np.zeros((Kt, 1, 12), np.int16)], 1)
+    return tm, tfr, rng
+
+
+def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
+    """K timed steps of one workload on this rank's GPU (barrier + synchronize on both sides, max over ranks), then an
+    untimed isolated pass (whole batch as one chunk on one stream) for the per-kernel durations.  Returns a dict."""
+    rate, eng_cfg, Kt, n_words = workload_setup(None, workload, Kt)
+    dev = torch.device("cuda", local_rank)
+    S = synth.buf_len_for(T, rate)
+    eng = Engine(max_frames=MAX_FRAMES, device=local_rank, **eng_cfg)
+    bank = synth.word_bank(n_words)
+    tm, tfr, rng = make_templates(eng, bank, Kt, n_words, rate, dev)
     eng.set_templates_dense(tm, tfr.astype(np.uint32))
-    del tpcm, tvad, tmf
 
     # ---- this rank's shard of utterances, generated straight into HBM -------------------------------
     lo, hi = du.shard_bounds(world * B, world, rank)  # weak scaling: B utterances per rank
-    words = torch.from_numpy(rng.integers(0, N_WORDS, world * B))[lo:hi]
+    words = torch.from_numpy(rng.integers(0, n_words, world * B))[lo:hi]
     pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev, rate=rate)
     # N > 1: two output sets, so the all-gather of step i (RCCL stream) overlaps the kernels of step i+1
     outs = [eng.alloc_outputs(B, dev, mfcc=True, vad=True) for _ in range(2 if world > 1 else 1)]
     out = outs[0]
-    xchg = du.ScoreExchange(world, [torch.empty(world * B, K, dtype=torch.int32, device=dev) for _ in outs]) if world > 1 else None
+    xchg = du.ScoreExchange(world, [torch.empty(world * B, Kt, dtype=torch.int32, device=dev) for _ in outs]) if world > 1 else None
     n_step = [0]
 
     def step():
@@ -124,7 +197,7 @@ def main():
             xchg.drain()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     finish()
     eng.set_profiling(True)
@@ -132,7 +205,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     finish()  # every step's kernels AND its all-gather are complete
     if world > 1:
@@ -153,103 +226,271 @@ def main():
     # sanity on real outputs (outside the timed region): every utterance must have exactly T frames
     res = results_from_torch(out["results"])
     assert (res["status"] == 0).all() and (res["frm_num"] == T).all(), "workload is not 256-frame utterances"
-    acc = float((res["best_tpl"] % N_WORDS == words.numpy()).mean())
+    acc = float((res["best_tpl"] % n_words == words.numpy()).mean())
     if xchg is not None:  # the gathered matrix holds every rank's scores in global utterance order
         g = xchg.gathered[0][rank * B:(rank + 1) * B]
         assert torch.equal(g, out["scores"]), "all-gather did not return this rank's shard in place"
+    return dict(dt=dt, stage=stage, stage_iso=stage_iso, acc=acc, eng=eng, pcm=pcm, out=out, tm=tm, tfr=tfr, S=S, rate=rate,
+                eng_cfg=eng_cfg, K=Kt, n_words=n_words)
 
+
+def workload_name(workload, B, Kt):
+    if workload == "ext":
+        return (f"BASELINE configs[4] EXTENSION (no reference counterpart): 16 kHz / 512-pt / 40 Mel, batch={B} utterances x "
+                f"{Kt} templates per GPU, 256 frames")
+    idx = 2 if (B, Kt) == (65536, 100) else 1 if (B, Kt) == (4096, 10) else "-"
+    return (f"BASELINE configs[{idx}]: batch={B} utterances x {Kt} templates per GPU, 256 frames, 12-coef MFCC, 8 kHz "
+            "25360-sample capture buffers")
+
+
+def mfcc_bytes(rate):
+    C = 12
+    return mfcc_kernel_bytes_per_utt(T, C) if rate == 1 else 2 * (160 * (T - 1) + 320 + 1) + 2 * T * C + 48
+
+
+def other_config(workload, B, Kt, steps, local_rank, cpu_n):
+    """one `other_configs` entry: a parity-test shape of BASELINE.json timed for a few steps under the same rules as the
+    headline (inputs resident, barrier-free at N = 1, synchronize on both sides) + a CPU parity check on a sample"""
+    m = measure(workload, B, Kt, steps, 1, 0, 1, local_rank, None)
+    by = mfcc_bytes(m["rate"])
+    iso = m["stage_iso"]
+    e = {"workload": workload_name(workload, B, m["K"]), "value": B * steps / m["dt"], "unit": "utterances/s",
+         "ms_per_step": m["dt"] / steps * 1e3, "steps": steps, "warmup": 1,
+         "kernel_ms_isolated": {k: iso[k] for k in ("vad", "mfcc", "dtw", "argmin", "total")},
+         "roofline_hbm_frac_dominant_kernel": by * B / (iso["mfcc"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         "top1_word_accuracy": m["acc"]}
+    if cpu_n:
+        cb = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], min(cpu_n, B), m["eng_cfg"])
+        e["parity_on_sample"] = {"identical": bool(cb["gpu_results_identical_on_sample"] and
+                                                   cb.get("port", cb)["gpu_results_identical_on_sample"]),
+                                 "utterances": min(cpu_n, B), "checker": cb["kind"] +
+                                 (" (the reference's own objects) + port" if cb["kind"] == "reference" else
+                                  " (the parametrised CPU restatement; this front end has no reference counterpart)"),
+                                 "cpu_utt_per_s": cb["value"], "cpu_cores": cb["cores"]}
+    if workload == "ext":
+        e["note"] = "EXTENSION: no reference counterpart (cr4_fft_1024_stm32.s:214-215 converts 1024 points only); parity is against its own oracle"
+    m["eng"].close()
+    return e
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.launcher == "single":
+            return run_single_process(args)
+        return self_launch(args)
+    return run_rank(args)
+
+
+def run_rank(args):
+    rank, local_rank, world = du.env_rank()
+    # test hooks (tests/test_gpu_parity.py runs the N = 2 code path on a 1-GPU box): collective backend and a forced
+    # device ordinal.  The driver never sets them: N > 1 means one rank per GPU over RCCL.
+    backend = os.environ.get("SR_BENCH_BACKEND", "nccl")
+    if "SR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SR_BENCH_DEVICE"])
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: device {local_rank} requested but {torch.cuda.device_count()} MI355X visible "
+                         "(there is no CPU path; --gpus N needs N devices)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        du.init_process_group(backend, local_rank)
+    torch.cuda.set_device(local_rank)
+    B = args.batch
+    m = measure(args.workload, B, args.templates, args.steps, args.warmup, rank, world, local_rank, dist)
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = world * B * args.steps / dt
-        C = 12
-        by_path = algorithmic_bytes_per_utt(S, T, C, K)
-        by_mfcc = mfcc_kernel_bytes_per_utt(T, C) if rate == 1 else 2 * (160 * (T - 1) + 320 + 1) + 2 * T * C + 48
-        # the engine cuts a step into chunks on overlapping streams: each kernel is launched `launches` times per step,
-        # one launch covers B / launches utterances; stage[...] are per-launch durations (hipEvents on its stream)
-        launches = stage["launches_per_call"]
-        ach = by_mfcc * (B / launches) / (stage["mfcc"] * 1e-3) / 1e9
-        # the same kernel alone on the chip: ONE launch over all B utterances (the untimed extra pass)
-        ach_iso = by_mfcc * B / (stage_iso["mfcc"] * 1e-3) / 1e9
-        traffic = traffic_iso = traffic_src = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.workload == "ref" and os.path.exists(tpath):
-            try:  # the PMC passes measured one whole-batch launch over tj["B"] utterances; traffic scales with utterances
-                tj = json.load(open(tpath))
-                traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]
-                traffic_iso = tj["k_mfcc_hbm_bytes_per_launch"] * B / tj["B"]
-                traffic_src = tj.get("source")
-            except Exception:
-                traffic = traffic_iso = None
-        # What actually bounds the path: VALU issue.  Measured directly on this chip (profiles/r02/VALU_ISSUE.md,
-        # profiles/valu_issue_ubench.hip): in a mixed instruction stream every wave64 VALU instruction holds its SIMD's
-        # issue port for 4 cycles (a transcendental for 8); the 2-cycle rate of simple ops needs a pure run of them, which
-        # these kernels never have.  Ceiling = 1024 SIMDs x 2.4 GHz / 4 issue slots per second; the slots a step needs come
-        # from the committed PMC pass (SQ_ACTIVE_INST_VALU = 4-cycle issue slots, profiles/pmc_valu.json).
-        roofline_valu = None
-        vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
-        if args.workload == "ref" and os.path.exists(vpath):
-            try:
-                vj = json.load(open(vpath))
-                insts = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
-                slots = sum(v for k, v in vj.items() if k.endswith("_valu_slots_per_utt")) or insts
-                peak = 1024 * 2.4e9 / 4.0
-                achv = slots * B / (stage["total"] * 1e-3)
-                roofline_valu = {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "4-cycle issue slots/s",
-                                 "frac": achv / peak, "valu_slots_per_utt": slots, "valu_insts_per_utt": insts,
-                                 "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9, "source": vj.get("source"),
-                                 "rates_source": "profiles/r02/VALU_ISSUE.md (per-opcode s_memtime micro-benchmark)",
-                                 "note": "derived: slot counts from the committed PMC pass x this run's step time; the chip "
-                                         "clocks 2.3-2.4 GHz under this load, the ceiling assumes the nominal 2.4"}
-            except Exception:
-                roofline_valu = None
-        line = {
-            "metric": f"utterances/sec (256-frame, {K} templates)" if args.workload == "ref"
-            else "utterances/sec (EXTENSION: 16 kHz/512-pt/40 Mel, 256-frame, 500 templates; no reference counterpart)",
-            "value": value,
-            "unit": "utterances/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int32",
-            "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[{2 if (B, K) == (65536, 100) else 1 if (B, K) == (4096, 10) else '-'}]: "
-                                    f"batch={B} utterances x {K} templates per GPU, 256 frames, "
-                                    "12-coef MFCC, 8 kHz 25360-sample capture buffers") if args.workload == "ref" else
-                                   "BASELINE configs[4] EXTENSION: 16 kHz / 512-pt / 40 Mel, 256 frames x 500 templates",
-                       "batch_per_gpu": B, "templates": K, "frames": T, "buf_len": S,
-                       "parallelism": f"utterance-sharded x{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_mfcc", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": by_mfcc * B / launches, "kernel_ms": stage["mfcc"],
-                         "launches_per_step": launches, "utterances_per_launch": B / launches,
-                         "isolated": {"achieved": ach_iso, "frac": ach_iso / HBM_PEAK_GBS, "kernel_ms": stage_iso["mfcc"],
-                                      "utterances_per_launch": B, "algorithmic_bytes_per_launch": by_mfcc * B,
-                                      "traffic": traffic_iso,
-                                      "note": "the same kernel alone on the chip: one launch over the whole batch (untimed "
-                                              "extra pass); this is the figure the rocprof 'whole batch' rows agree with"},
-                         "note": "achieved/frac: launches of the TIMED steps (B/launches utterances each, overlapping two other "
-                                 "chunks' kernels on other streams, so each launch owns only part of the chip); the path is "
-                                 "integer-VALU-bound, not HBM-bound (DESIGN.md 3.2): see roofline_valu"},
-            "roofline_path": {"bytes_per_utt": by_path, "achieved": by_path * B / (stage["total"] * 1e-3) / 1e9,
-                              "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "note": "whole step (all chunks, fork -> join on the launch stream)"},
-            "roofline_valu": roofline_valu,
-            "kernel_ms": stage,
-            "kernel_ms_isolated": {**stage_iso, "note": "untimed extra pass: whole batch as one chunk on one stream (no overlap)"},
-            "top1_word_accuracy": acc,
-        }
+        line = headline(args, m, world, backend)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pcm, eng, out, tm, tfr, args.cpu_sample, eng_cfg)
+            line["cpu_baseline"] = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], args.cpu_sample, m["eng_cfg"])
             if args.workload == "ref":
                 line["cpu_reference_objects"] = cpu_reference_objects(local_rank)
+        default_shape = args.workload == "ref" and (B, m["K"]) == (65536, 100)
+        if world == 1 and (default_shape or args.other_scale > 1) and not args.no_other_configs:
+            # the other single-GPU shapes BASELINE.json names, under the same clock (never part of `value`)
+            del m["pcm"], m["out"]
+            m["eng"].close()
+            torch.cuda.empty_cache()
+            cpu_n = 0 if args.no_cpu_baseline else 256
+            sc = args.other_scale
+            line["other_configs"] = [other_config("ref", 4096 // sc, 10, args.other_steps, local_rank, cpu_n),
+                                     other_config("ext", 65536 // sc, 500, args.other_steps, local_rank, cpu_n and 128)]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def headline(args, m, world, backend="nccl", launcher=None):
+    """the ONE JSON line of the contract, from a measure() result"""
+    B, Kt, S, rate = args.batch, m["K"], m["S"], m["rate"]
+    stage, stage_iso, dt = m["stage"], m["stage_iso"], m["dt"]
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    C = 12
+    by_path = algorithmic_bytes_per_utt(S, T, C, Kt)
+    by_mfcc = mfcc_bytes(rate)
+    # the engine cuts a step into chunks on overlapping streams: each kernel is launched `launches` times per step,
+    # one launch covers B / launches utterances; stage[...] are per-launch durations (hipEvents on its stream)
+    launches = stage["launches_per_call"]
+    ach_ovl = by_mfcc * (B / launches) / (stage["mfcc"] * 1e-3) / 1e9
+    # the same kernel alone on the chip: ONE launch over all B utterances (the extra pass right after the timed steps)
+    ach_iso = by_mfcc * B / (stage_iso["mfcc"] * 1e-3) / 1e9
+    traffic = traffic_iso = traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if args.workload == "ref" and os.path.exists(tpath):
+        try:  # the PMC passes measured one whole-batch launch over tj["B"] utterances; traffic scales with utterances
+            tj = json.load(open(tpath))
+            traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]
+            traffic_iso = tj["k_mfcc_hbm_bytes_per_launch"] * B / tj["B"]
+            traffic_src = tj.get("source")
+        except Exception:
+            traffic = traffic_iso = None
+    # What actually bounds the path: VALU issue.  Measured directly on this chip (profiles/r02/VALU_ISSUE.md,
+    # profiles/valu_issue_ubench.hip): in a mixed instruction stream every wave64 VALU instruction holds its SIMD's
+    # issue port for 4 cycles (a transcendental for 8); the 2-cycle rate of simple ops needs a pure run of them, which
+    # these kernels never have.  Ceiling = 1024 SIMDs x 2.4 GHz / 4 issue slots per second; the slots a step needs come
+    # from the committed PMC pass (SQ_ACTIVE_INST_VALU = 4-cycle issue slots, profiles/pmc_valu.json).
+    roofline_valu = None
+    vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+    if args.workload == "ref" and Kt == 100 and os.path.exists(vpath):
+        try:
+            vj = json.load(open(vpath))
+            insts = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
+            slots = sum(v for k, v in vj.items() if k.endswith("_valu_slots_per_utt")) or insts
+            peak = 1024 * 2.4e9 / 4.0
+            achv = slots * B / (stage["total"] * 1e-3)
+            roofline_valu = {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "4-cycle issue slots/s",
+                             "frac": achv / peak, "valu_slots_per_utt": slots, "valu_insts_per_utt": insts,
+                             "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9, "source": vj.get("source"),
+                             "rates_source": "profiles/r02/VALU_ISSUE.md (per-opcode s_memtime micro-benchmark)",
+                             "note": "derived: slot counts from the committed PMC pass x this run's step time; the chip "
+                                     "clocks 2.3-2.4 GHz under this load, the ceiling assumes the nominal 2.4"}
+        except Exception:
+            roofline_valu = None
+    par = f"utterance-sharded x{world}"
+    if world > 1:
+        par += ", RCCL all-gather of scores" if backend == "nccl" else f", all-gather of scores over {backend} (TEST HOOK, not RCCL)"
+    line = {
+        "metric": f"utterances/sec (256-frame, {Kt} templates)" if args.workload == "ref"
+        else f"utterances/sec (EXTENSION: 16 kHz/512-pt/40 Mel, 256-frame, {Kt} templates; no reference counterpart)",
+        "value": value,
+        "unit": "utterances/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {"workload": workload_name(args.workload, B, Kt),
+                   "batch_per_gpu": B, "templates": Kt, "frames": T, "buf_len": S, "parallelism": par},
+        # HBM roofline of the dominant kernel, as the contract defines it: algorithmic bytes of one launch / the duration
+        # of that launch.  achieved / frac = the kernel ALONE on the chip, one launch over the whole batch (hipEvents on
+        # its stream, in the pass right after the timed steps) -- the figure profiles/*_rocprof_summary.csv reproduces.
+        "roofline": {"bound": "hbm", "kernel": "k_mfcc" if rate == 1 else "k_mfcc_ext", "achieved": ach_iso,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_iso / HBM_PEAK_GBS, "traffic": traffic_iso,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by_mfcc * B,
+                     "kernel_ms": stage_iso["mfcc"], "launches_per_step": 1, "utterances_per_launch": B,
+                     "measured": "hipEvents around the launch on its own stream; whole batch as ONE launch, kernel alone on "
+                                 "the chip (extra pass right after the timed steps; agrees with the rocprof 'whole batch' row)",
+                     "overlapped": {"achieved": ach_ovl, "frac": ach_ovl / HBM_PEAK_GBS, "kernel_ms": stage["mfcc"],
+                                    "launches_per_step": launches, "utterances_per_launch": B / launches,
+                                    "algorithmic_bytes_per_launch": by_mfcc * B / launches, "traffic": traffic,
+                                    "note": "launches of the TIMED steps: each covers B/launches utterances and shares the "
+                                            "chip with two other chunks' kernels on other streams, so the per-launch "
+                                            "durations overlap and do not add up to the step; not a fraction of the chip"},
+                     "note": "the path is integer-VALU-issue-bound, not HBM-bound (DESIGN.md 3.2): see roofline_valu"},
+        "roofline_path": {"bytes_per_utt": by_path, "achieved": by_path * B / (stage["total"] * 1e-3) / 1e9,
+                          "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "note": "whole step (all chunks, fork -> join on the launch stream)"},
+        "roofline_valu": roofline_valu,
+        "kernel_ms": stage,
+        "kernel_ms_isolated": {**stage_iso, "note": "untimed extra pass: whole batch as one chunk on one stream (no overlap)"},
+        "top1_word_accuracy": m["acc"],
+    }
+    if launcher:
+        line["launcher"] = launcher
+    return line
+
+
+def run_single_process(args):
+    """--launcher single: ONE process drives the N GPUs through the C ABI (sr_multi_*, csrc/sr_multi.cpp): one engine
+    and one stream per device, device-resident shards, and per step one grouped in-place ncclAllGather of the score
+    matrix on the same streams (the exchange step of main.c:279-291's slot scan, for every utterance, on every GPU)."""
+    from stm32_speech_recognition_amd.engine import MultiEngine
+    n, B = args.gpus, args.batch
+    if args.workload != "ref":
+        raise SystemExit("--launcher single runs the reference workload only")
+    devs = list(range(n))
+    if "SR_BENCH_DEVICE" in os.environ:  # test hook: all "ranks" on one device (needs SR_MULTI_TEST_ALLOW_DUP=1 + the fake RCCL)
+        devs = [int(os.environ["SR_BENCH_DEVICE"])] * n
+    if not torch.cuda.is_available() or max(devs) >= torch.cuda.device_count():
+        raise SystemExit(f"--gpus {n} but {torch.cuda.device_count()} MI355X visible (there is no CPU path)")
+    rate, eng_cfg, Kt, n_words = workload_setup(None, "ref", args.templates)
+    S = synth.buf_len_for(T, rate)
+    me = MultiEngine(devs, max_frames=MAX_FRAMES)
+    bank = synth.word_bank(n_words)
+    e0 = me.engine(0)
+    tm, tfr, rng = make_templates(e0, bank, Kt, n_words, rate, torch.device("cuda", devs[0]))
+    me.set_templates_dense(tm, tfr.astype(np.uint32))
+    words = torch.from_numpy(rng.integers(0, n_words, n * B))
+    pl, rl, al, sl = [], [], [], []
+    for i, d in enumerate(devs):
+        dev = torch.device("cuda", d)
+        pl.append(synth.make_utterances(words[i * B:(i + 1) * B], [T] * B, seed=1000 + i, bank=bank, S=S, device=dev, rate=rate))
+        rl.append(torch.empty(B, 4, dtype=torch.int32, device=dev))
+        al.append(torch.empty(n * B, Kt, dtype=torch.int32, device=dev))
+        sl.append(torch.cuda.Stream(device=dev))
+
+    def sync():
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+
+    sync()
+    for _ in range(args.warmup):
+        me.recognize_dev(pl, rl, al, streams=sl)
+    sync()
+    e0.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        me.recognize_dev(pl, rl, al, streams=sl)
+    sync()
+    dt = time.perf_counter() - t0
+    stage = e0.stage_ms()
+    e0.set_profiling(False)
+    e0.set_pipeline(streams=1)
+    e0.set_profiling(True)
+    out0 = e0.alloc_outputs(B, torch.device("cuda", devs[0]), mfcc=False, vad=False)
+    for _ in range(2):
+        e0.recognize_dev(pl[0], out0, stream=sl[0].cuda_stream)
+    sync()
+    stage_iso = e0.stage_ms()
+    e0.set_profiling(False)
+    e0.set_pipeline()
+    # every device holds the whole matrix; its own block is what its kernels wrote; results are 256-frame matches
+    ref_all = al[0].cpu()
+    accs = []
+    for i in range(n):
+        assert torch.equal(al[i].cpu(), ref_all), f"device {i}: gathered score matrix differs from device 0's"
+        res = results_from_torch(rl[i])
+        assert (res["status"] == 0).all() and (res["frm_num"] == T).all(), "workload is not 256-frame utterances"
+        accs.append((res["best_tpl"] % n_words == words[i * B:(i + 1) * B].numpy()))
+    assert torch.equal(ref_all[:B], out0["scores"].cpu()), "device 0's block differs from its single-engine scores"
+    m = dict(dt=dt, stage=stage, stage_iso=stage_iso, acc=float(np.concatenate(accs).mean()), S=S, rate=rate, K=Kt)
+    line = headline(args, m, n, launcher="single (one process, sr_multi_* C ABI: one engine + stream per device, grouped "
+                                         "in-place ncclAllGather per step)")
+    line["config"]["parallelism"] = f"utterance-sharded x{n}, RCCL all-gather of scores (single process, sr_multi)"
+    if os.environ.get("SR_RCCL_LIBRARY"):
+        line["config"]["parallelism"] += " -- TEST HOOK: collective library " + os.environ["SR_RCCL_LIBRARY"]
+    print(json.dumps(line), flush=True)
+    me.close()
+    return 0
 
 
 def usable_cores():
@@ -372,14 +613,14 @@ def cpu_reference_objects(device, n=32, Kr=100):
     T, S = 119, 16000
     ref, orc = ol.RefLib(), ol.Oracle(max_frames=T)
     eng = Engine(max_frames=T, device=device)
-    bank = synth.word_bank(N_WORDS)
+    bank = synth.word_bank(N_WORDS_DEFAULT)
     rng = np.random.default_rng(7)
     tfr = rng.integers(60, T + 1, Kr)
-    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(Kr) % N_WORDS, tfr, seed=5, bank=bank, S=S))
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(Kr) % N_WORDS_DEFAULT, tfr, seed=5, bank=bank, S=S))
     store, st = eng.train_store(tp, np.arange(Kr), n_slots=Kr)       # save_mdl flash image (main.c:121-138)
     assert (st == 0).all()
     eng.set_templates_store(store)
-    words = rng.integers(0, N_WORDS, n)
+    words = rng.integers(0, N_WORDS_DEFAULT, n)
     pcm = synth.as_u16_numpy(synth.make_utterances(words, [T] * n, seed=6, bank=bank, S=S))
     tm = np.zeros((Kr, T + 1, 12), np.int16)
     for k in range(Kr):
@@ -406,4 +647,4 @@ def cpu_reference_objects(device, n=32, Kr=100):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

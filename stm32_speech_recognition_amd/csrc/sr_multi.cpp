@@ -6,9 +6,9 @@
 // a process that already carries a RCCL (PyTorch) shares that copy.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstring>
@@ -24,6 +24,15 @@ int set_error(int code, const std::string &msg);  // sr_engine.cpp: thread-local
 using sr::set_error;
 
 namespace {
+
+// The handful of RCCL declarations this file needs, stated locally (values as in rccl.h of ROCm 7: ncclResult_t 0 =
+// ncclSuccess, ncclDataType_t 3 = ncclUint32): the library is bound at run time, so a ROCm install without the rccl
+// development headers still builds libsr_engine.so.
+typedef int ncclResult_t;
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint32 = 3;
 
 struct Rccl {
     void *lib = nullptr;
@@ -41,12 +50,22 @@ Rccl *rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
+        // SR_RCCL_LIBRARY: explicit path of the collective library (a site-specific RCCL build; the in-process test
+        // double tests/fake_rccl/librccl.so.1).  Bound RTLD_LOCAL so that its symbols never shadow a RCCL the process
+        // already carries.
+        const char *override_path = getenv("SR_RCCL_LIBRARY");
+        if (override_path && *override_path) {
+            r.lib = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.lib) break;
+            }
         }
         if (!r.lib) {
-            r.err = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();
+            const char *why = dlerror();
+            r.err = std::string("cannot load RCCL (") + (override_path && *override_path ? override_path : "librccl.so.1") +
+                    "): " + (why ? why : "unknown dlopen failure");
             return;
         }
         auto sym = [&](const char *n) {
@@ -96,8 +115,38 @@ struct sr_multi {
     std::vector<sr_result *> d_res;
     std::vector<uint32_t *> d_all;
     std::vector<size_t> cap_pcm, cap_res, cap_all;
-    uint32_t buf_len_max = 0;
+    // false after a template upload that reached only some of the devices: the engines then disagree about the store,
+    // and every recognise call is refused until a later upload succeeds on all of them
+    bool store_consistent = true;
 };
+
+// One upload per device.  The single-engine upload is failure-atomic (a failed call keeps the old store), so a failure
+// on the FIRST device leaves every device on the old store and the handle stays usable; a failure on a later device
+// leaves the devices before it on the new store: the handle is marked inconsistent and recognise calls are refused
+// (mixed stores would be gathered as one mis-strided score matrix) until an upload succeeds everywhere.
+template <class F>
+static int replicate(sr_multi *m, F upload)
+{
+    for (size_t i = 0; i < m->eng.size(); i++)
+        if (int rc = upload(m->eng[i])) {
+            if (i > 0) m->store_consistent = false;
+            return rc;
+        }
+    m->store_consistent = true;
+    return SR_OK;
+}
+
+// every recognise entry: the store must be the same everywhere (K is the stride of the gathered matrix)
+static int check_store(const sr_multi *m, uint32_t *K)
+{
+    if (!m->store_consistent)
+        return set_error(SR_ERR_NO_TEMPLATES, "template stores differ between devices (an earlier sr_multi_set_templates* failed part-way): upload again");
+    *K = sr_num_templates(m->eng[0]);
+    if (!*K) return set_error(SR_ERR_NO_TEMPLATES, "no templates set");
+    for (sr_engine *e : m->eng)
+        if (sr_num_templates(e) != *K) return set_error(SR_ERR_NO_TEMPLATES, "template count differs between devices");
+    return SR_OK;
+}
 
 extern "C" {
 
@@ -105,9 +154,13 @@ int sr_multi_create(const sr_config *cfg, const int *devices, uint32_t n_dev, sr
 {
     if (!cfg || !devices || !out || n_dev == 0 || n_dev > 64) return set_error(SR_ERR_BAD_ARG, "null argument / device count 1..64");
     *out = nullptr;
-    for (uint32_t i = 0; i < n_dev; i++)
-        for (uint32_t j = 0; j < i; j++)
-            if (devices[i] == devices[j]) return set_error(SR_ERR_BAD_ARG, "duplicate device ordinal");
+    // SR_MULTI_TEST_ALLOW_DUP=1 (tests only): several "ranks" on one device, so that the N > 1 bookkeeping can be
+    // executed on a 1-GPU box against the in-process collective double (a real RCCL refuses duplicate devices itself)
+    const char *dup = getenv("SR_MULTI_TEST_ALLOW_DUP");
+    if (!(dup && dup[0] == '1'))
+        for (uint32_t i = 0; i < n_dev; i++)
+            for (uint32_t j = 0; j < i; j++)
+                if (devices[i] == devices[j]) return set_error(SR_ERR_BAD_ARG, "duplicate device ordinal");
     Rccl *R = rccl();
     if (!R->err.empty()) return set_error(SR_ERR_NO_DEVICE, R->err);
     DevGuard guard;
@@ -170,18 +223,14 @@ sr_engine *sr_multi_engine(sr_multi *m, uint32_t i) { return (m && i < m->eng.si
 int sr_multi_set_templates(sr_multi *m, const void *store, uint32_t n_slots, uint32_t stride_bytes)
 {
     if (!m) return set_error(SR_ERR_BAD_ARG, "null handle");
-    for (sr_engine *e : m->eng)
-        if (int rc = sr_set_templates(e, store, n_slots, stride_bytes)) return rc;  // replicated: 0.8 MB at K = 100
-    return SR_OK;
+    return replicate(m, [&](sr_engine *e) { return sr_set_templates(e, store, n_slots, stride_bytes); });  // 0.8 MB at K = 100
 }
 
 int sr_multi_set_templates_dense(sr_multi *m, const int16_t *mfcc, const uint32_t *frames, const uint8_t *valid,
                                  uint32_t n_templates, uint32_t tpl_stride)
 {
     if (!m) return set_error(SR_ERR_BAD_ARG, "null handle");
-    for (sr_engine *e : m->eng)
-        if (int rc = sr_set_templates_dense(e, mfcc, frames, valid, n_templates, tpl_stride)) return rc;
-    return SR_OK;
+    return replicate(m, [&](sr_engine *e) { return sr_set_templates_dense(e, mfcc, frames, valid, n_templates, tpl_stride); });
 }
 
 // Device-resident shards.  Device i recognises its B_per_dev utterances (d_pcm[i]) and writes its block of the score
@@ -193,8 +242,9 @@ int sr_multi_recognize_dev(sr_multi *m, const uint16_t *const *d_pcm, uint64_t p
                            void *const *streams)
 {
     if (!m || !d_pcm || !d_results || !d_scores_all) return set_error(SR_ERR_BAD_ARG, "null argument");
-    const uint32_t n = (uint32_t)m->dev.size(), K = sr_num_templates(m->eng[0]);
-    if (!K) return set_error(SR_ERR_NO_TEMPLATES, "no templates set");
+    const uint32_t n = (uint32_t)m->dev.size();
+    uint32_t K = 0;
+    if (int rc = check_store(m, &K)) return rc;
     if (B_per_dev == 0) return SR_OK;
     Rccl *R = rccl();
     DevGuard guard;
@@ -233,8 +283,9 @@ int sr_multi_recognize(sr_multi *m, const uint16_t *pcm, uint64_t pcm_stride, ui
     if (!m || !pcm || !results) return set_error(SR_ERR_BAD_ARG, "null argument");
     if (B == 0) return SR_OK;
     if (buf_len > pcm_stride) return set_error(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
-    const uint32_t n = (uint32_t)m->dev.size(), K = sr_num_templates(m->eng[0]);
-    if (!K) return set_error(SR_ERR_NO_TEMPLATES, "no templates set");
+    const uint32_t n = (uint32_t)m->dev.size();
+    uint32_t K = 0;
+    if (int rc = check_store(m, &K)) return rc;
     const uint32_t per = (B + n - 1) / n;
     const uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
     DevGuard guard;

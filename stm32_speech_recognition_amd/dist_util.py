@@ -14,7 +14,11 @@ def env_rank():
 
 def init_process_group(backend, local_rank=0):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
+    # every rank must name the SAME rendezvous port, so a rank cannot probe for a free one by itself: the launcher
+    # (torch.distributed.run, or bench.py's own self_launch, which probes 127.0.0.1 for a free port) hands it over.
+    if "MASTER_PORT" not in os.environ:
+        raise RuntimeError("MASTER_PORT is not set: start the ranks with torch.distributed.run or `python bench.py --gpus N` "
+                           "(which picks a free port), or export one port for all ranks")
     # the host driver of these boxes only supports dmabuf IPC: without this RCCL / cross-process tensor sharing fails with
     # "hipIpcGetMemHandle: invalid argument" (stated for this image; already exported in its environment, kept as a default)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

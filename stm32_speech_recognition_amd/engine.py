@@ -105,13 +105,22 @@ class Engine:
         self.max_frames = max_frames
         self.noise_len = (cfg.fs // 1000) * cfg.noise_len_ms
 
+    @classmethod
+    def borrowed(cls, handle, cfg, max_frames):
+        """a view of an sr_engine handle somebody else owns (sr_multi_engine): same methods, never destroyed from here"""
+        e = cls.__new__(cls)
+        e.L, e.cfg, e.h, e.max_frames, e._borrowed = load_library(), cfg, C.c_void_p(handle), max_frames, True
+        e.noise_len = (cfg.fs // 1000) * cfg.noise_len_ms
+        return e
+
     def _check(self, rc):
         if rc != 0:
             raise SrError(f"sr_engine error {rc}: {self.L.sr_last_error().decode()}")
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.sr_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.L.sr_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -374,12 +383,24 @@ class MultiEngine:
         self._check(self.L.sr_multi_recognize(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B), _vp(res), _vp(sc)))
         return res, sc
 
-    def recognize_dev(self, pcm_list, results_list, scores_all_list, buf_len=None):
+    def engine(self, i):
+        """the sr_engine of devices[i] (sr_multi_engine), as a borrowed Engine: profiling hooks, stage-level calls"""
+        self.L.sr_multi_engine.restype = C.c_void_p
+        h = self.L.sr_multi_engine(self.h, C.c_uint32(i))
+        if not h:
+            raise SrError(f"sr_multi_engine({i}): no such device")
+        cfg = Config.from_buffer_copy(self.cfg)
+        cfg.device = self.devices[i]
+        return Engine.borrowed(h, cfg, self.max_frames)
+
+    def recognize_dev(self, pcm_list, results_list, scores_all_list, buf_len=None, streams=None):
         """device-resident shards: torch tensors per device (pcm int16/uint16 [Bp, S], results int32 [Bp, 4],
-        scores_all int32 [n_dev*Bp, K]); synchronous (internal streams)."""
+        scores_all int32 [n_dev*Bp, K]).  streams = None: the handle's own streams, returns when they have drained;
+        streams = one torch.cuda.Stream per device: asynchronous on those streams."""
         n = len(self.devices)
         Bp, S = pcm_list[0].shape
         arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        st = None if streams is None else (C.c_void_p * n)(*[s.cuda_stream for s in streams])
         self._check(self.L.sr_multi_recognize_dev(self.h, arr(pcm_list), C.c_uint64(pcm_list[0].stride(0)),
                                                   C.c_uint32(S if buf_len is None else buf_len), C.c_uint32(Bp),
-                                                  arr(results_list), arr(scores_all_list), None))
+                                                  arr(results_list), arr(scores_all_list), st))

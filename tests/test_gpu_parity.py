@@ -658,32 +658,30 @@ def test_template_store_swap_while_work_is_in_flight(golden):
 # ----------------------------------------------------------------------------- multi-GPU surface of the C ABI
 def _multi_case(devices, golden):
     """sr_multi_* on `devices`: sharded recognition + RCCL all-gather == the single-engine answer, host and device API"""
-    from stm32_speech_recognition_amd.engine import Engine, MultiEngine, results_from_torch
-    pcm = np.concatenate([golden["pcm"], golden["pcm"][::-1][:5]])        # 37 captures: uneven shards on 2+ devices
-    e1 = Engine(device=devices[0])
-    e1.set_templates_store(golden["store"])
-    want = e1.recognize(pcm, want_mfcc=False, want_vad=False)
-    me = MultiEngine(devices)
-    me.set_templates_store(golden["store"])
-    res, sc = me.recognize(pcm)
-    for f in ("best_tpl", "min_dis", "frm_num", "status"):
-        assert np.array_equal(res[f], want["results"][f]), f
-    assert np.array_equal(sc, want["scores"])
-    # device-resident shards, equal size: every device ends up with the whole score matrix
-    n, Bp, K = len(devices), 12, me.K
-    pl, rl, al = [], [], []
-    for i, d in enumerate(devices):
-        dev = torch.device("cuda", d)
-        pl.append(torch.from_numpy(pcm[i * Bp:(i + 1) * Bp].view(np.int16)).to(dev))
-        rl.append(torch.zeros(Bp, 4, dtype=torch.int32, device=dev))
-        al.append(torch.full((n * Bp, K), -1, dtype=torch.int32, device=dev))
-    me.recognize_dev(pl, rl, al)
-    for i in range(n):
-        assert np.array_equal(al[i].cpu().numpy().view(np.uint32), want["scores"][:n * Bp]), i
-        r = results_from_torch(rl[i])
-        assert np.array_equal(r["best_tpl"], want["results"]["best_tpl"][i * Bp:(i + 1) * Bp])
-    me.close()
-    e1.close()
+    from multi_case import multi_case
+    multi_case(devices, golden)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_multi_gpu_bookkeeping_with_in_process_collective_double(n):
+    """The N > 1 index arithmetic of csrc/sr_multi.cpp (block offsets of the in-place all-gather, padded last shard,
+    EMPTY last shard when B < n, read-back from the owning devices / device 0) executed on this 1-GPU box: n ranks on
+    device 0 (SR_MULTI_TEST_ALLOW_DUP=1) over tests/fake_rccl/librccl.so.1 (SR_RCCL_LIBRARY), an in-process stand-in
+    that performs the all-gather as stream-ordered device copies between the ranks' buffers.  Own process: the
+    collective library is bound once per process, and the other tests of this module use the real RCCL."""
+    import json
+    import subprocess
+    import multi_case as mc
+    assert os.path.exists(mc.FAKE_RCCL), "tests/fake_rccl/librccl.so.1 missing: run __graft_entry__.build()"
+    env = dict(os.environ, SR_RCCL_LIBRARY=mc.FAKE_RCCL, SR_MULTI_TEST_ALLOW_DUP="1")
+    Bs = [37, 24, n - 1, 1]                 # uneven shards; even shards; B < n (empty last shard); a single capture
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "multi_case.py"), ",".join(["0"] * n),
+                        ",".join(map(str, Bs))], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    rep = json.loads([l for l in p.stdout.splitlines() if l.startswith("MULTI_CASE ")][-1][len("MULTI_CASE "):])
+    assert [c["B"] for c in rep["cases"]] == Bs and all(c["n"] == n for c in rep["cases"])
+    # the double really carried the exchange: every gather is n*(n-1) copies (the own block is in place)
+    assert rep["fake_allgathers"] >= 2 * len(Bs) and rep["fake_copies"] == rep["fake_allgathers"] * n * (n - 1), rep
 
 
 def test_multi_gpu_c_abi_single_device(golden):
@@ -695,22 +693,93 @@ def test_multi_gpu_c_abi_two_devices(golden):
     _multi_case([0, 1], golden)
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X in one node")
-def test_bench_two_ranks_over_rccl():
-    """bench.py exactly as the driver launches it at N = 2: one rank per GPU, backend nccl (= RCCL over xGMI)"""
+def _run_bench(extra, env_extra, timeout=900):
+    """bench.py as a PLAIN command (no launcher, no WORLD_SIZE / RANK in the environment) -> (the one JSON line, stderr)"""
     import json
     import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                              "SR_BENCH_BACKEND", "SR_BENCH_DEVICE", "SR_RCCL_LIBRARY",
+                                                              "SR_MULTI_TEST_ALLOW_DUP")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                       timeout=timeout, cwd=root)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]       # exactly one line on stdout
+    return json.loads(lines[0]), p.stderr
+
+
+def test_bench_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE: the script starts its two ranks itself.  On
+    this 1-GPU box the ranks share device 0 and exchange over gloo (test hooks); with two devices the next test runs
+    the same command over RCCL."""
+    j, _ = _run_bench(["--gpus", "2", "--batch", "4096", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                      dict(SR_BENCH_BACKEND="gloo", SR_BENCH_DEVICE="0"))
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["launcher"].startswith("ranks")
+    assert j["config"]["batch_per_gpu"] == 4096 and "all-gather" in j["config"]["parallelism"]
+    assert abs(j["value"] - 2 * 4096 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
+    assert j["top1_word_accuracy"] == 1.0
+
+
+def test_bench_plain_command_single_process_launcher():
+    """`python bench.py --gpus 2 --launcher single`: ONE process over the C ABI (sr_multi_create on two "devices",
+    sr_multi_recognize_dev per step, one grouped all-gather).  On this 1-GPU box both ranks sit on device 0 and the
+    collective library is the in-process double (tests/fake_rccl); with two devices the next test uses RCCL."""
+    import multi_case as mc
+    j, _ = _run_bench(["--gpus", "2", "--launcher", "single", "--batch", "4096", "--steps", "2", "--warmup", "1"],
+                      dict(SR_BENCH_DEVICE="0", SR_RCCL_LIBRARY=mc.FAKE_RCCL, SR_MULTI_TEST_ALLOW_DUP="1"))
+    assert j["n_gpus"] == 2 and j["launcher"].startswith("single") and "TEST HOOK" in j["config"]["parallelism"]
+    assert abs(j["value"] - 2 * 4096 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
+    assert j["top1_word_accuracy"] == 1.0 and j["roofline"]["frac"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X in one node")
+@pytest.mark.parametrize("launcher", ["ranks", "single"])
+def test_bench_plain_command_over_rccl(launcher):
+    """the driver's own line at N = 2 (`python bench.py --gpus 2 ...`, nothing else): one rank per GPU over RCCL, and
+    the single-process launcher over the same RCCL"""
+    j, _ = _run_bench(["--gpus", "2", "--launcher", launcher, "--batch", "4096", "--steps", "2", "--warmup", "1",
+                       "--no-cpu-baseline"], {})
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "RCCL" in j["config"]["parallelism"]
+    assert "TEST HOOK" not in j["config"]["parallelism"] and j["top1_word_accuracy"] == 1.0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X in one node")
+def test_bench_two_ranks_over_rccl():
+    """bench.py under torch.distributed.run at N = 2 (WORLD_SIZE set by the launcher): one rank per GPU, backend nccl"""
+    import json
+    import subprocess
+    from bench import free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("SR_BENCH_BACKEND", None)
     env.pop("SR_BENCH_DEVICE", None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "bench.py"),
                           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]
+
+
+def test_bench_other_configs_and_roofline_keys():
+    """the N = 1 line: `roofline` = the dominant kernel alone on the chip (one launch over the whole batch), the chunked
+    launches of the timed steps under roofline.overlapped, and configs[1] / configs[4] under other_configs (scaled down
+    here), each with a CPU parity check on a sample"""
+    j, _ = _run_bench(["--batch", "8192", "--steps", "2", "--warmup", "1", "--cpu-sample", "128", "--other-scale", "16",
+                       "--other-steps", "2"], {})
+    r = j["roofline"]
+    assert r["utterances_per_launch"] == 8192 and r["launches_per_step"] == 1 and 0 < r["frac"] < 1
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    assert r["overlapped"]["launches_per_step"] >= 2 and r["overlapped"]["utterances_per_launch"] < 8192
+    assert j["cpu_baseline"]["gpu_results_identical_on_sample"] is True
+    oc = j["other_configs"]
+    assert len(oc) == 2 and "configs[4] EXTENSION" in oc[1]["workload"] and "10 templates" in oc[0]["workload"]
+    for e in oc:
+        assert e["value"] > 0 and e["parity_on_sample"]["identical"] is True and e["kernel_ms_isolated"]["mfcc"] > 0
+        assert e["top1_word_accuracy"] == 1.0
 
 
 # ----------------------------------------------------------------------------- SURVEY 8(f) rows

@@ -114,3 +114,27 @@ def test_two_rank_allgather_of_scores():
         ref_mn = want.min(1)
         ref_best = np.array([int(np.argmax(row == row.min())) if row.min() != 0xFFFFFFFF else 0 for row in want])
         assert np.array_equal(mn, ref_mn.astype(np.int64)) and np.array_equal(best, ref_best)
+
+
+def test_bench_plain_command_starts_one_rank_per_gpu_and_fails_loudly_without_devices():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE must start its own ranks.  Without
+    a GPU here every rank refuses (there is no CPU path): non-zero exit code, nothing on stdout, both ranks named."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        return  # the GPU suite runs the real thing (test_bench_plain_command_launches_its_own_ranks)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "rank 0: device 0 requested" in p.stderr or "rank 1: device 1 requested" in p.stderr
+    assert "stopping the other ranks" in p.stderr
+
+
+def test_rank_without_master_port_is_refused(monkeypatch):
+    """no silent default port: two jobs on one node would collide on it"""
+    import pytest
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        du.init_process_group("gloo")
