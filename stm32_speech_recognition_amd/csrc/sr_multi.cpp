@@ -250,7 +250,9 @@ int sr_multi_recognize_dev(sr_multi *m, const uint16_t *const *d_pcm, uint64_t p
     DevGuard guard;
     const size_t block = (size_t)B_per_dev * K;
     for (uint32_t i = 0; i < n; i++) {
-        if (!d_pcm[i] || !d_results[i] || !d_scores_all[i]) return set_error(SR_ERR_BAD_ARG, "null per-device pointer");
+        if (!d_pcm[i] || !d_results[i] || !d_scores_all[i])
+            return set_error(SR_ERR_BAD_ARG, "null per-device pointer (device index " + std::to_string(i) + ": " +
+                                                 (!d_pcm[i] ? "d_pcm" : !d_results[i] ? "d_results" : "d_scores_all") + ")");
         hipStream_t s = streams ? (hipStream_t)streams[i] : m->st[i];
         if (int rc = sr_recognize_batch_dev(m->eng[i], d_pcm[i], pcm_stride, buf_len, B_per_dev, d_results[i],
                                             d_scores_all[i] + (size_t)i * block, nullptr, nullptr, s))

@@ -22,7 +22,9 @@ def multi_case(devices, golden, B=37):
 
     from stm32_speech_recognition_amd.engine import Engine, MultiEngine, results_from_torch
     n = len(devices)
-    pcm = np.concatenate([golden["pcm"], golden["pcm"][::-1]])[:B]     # B = 37: uneven shards on 2+ devices
+    g = golden["pcm"]                                                   # 12 captures
+    pcm = np.concatenate([g, g[::-1], g[3:], g[::-1][5:]])[:B]          # B = 37: uneven shards on 2+ devices
+    assert len(pcm) == B
     e1 = Engine(device=devices[0])
     e1.set_templates_store(golden["store"])
     want = e1.recognize(pcm, want_mfcc=False, want_vad=False)
