@@ -110,6 +110,7 @@ typedef struct sr_tables {
     int16_t *tw_kr;     /* [1020]            first  DCW column of the ST coefficient table, in table order */
     int16_t *tw_ki;     /* [1020]            second DCW column */
     uint32_t *log_thr;  /* [2220]            log_thr[m] = min{n : (u32)(log((double)n)*100) >= m} (host libm), [2219] = sentinel */
+    int8_t *tie_delta;  /* [32768]           DTW.C:59,156-184: T(g) = g*(g+2) + tie_delta[g] = min{d : (u32)sqrtf((float)d) >= g + 1} */
 } sr_tables;
 int sr_build_tables(const sr_config *cfg, const sr_tables *out);
 

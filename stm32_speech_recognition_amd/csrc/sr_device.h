@@ -22,6 +22,7 @@ struct DevTables {
     const uint32_t *tri_odd32;
     const uint32_t *w512_a;    // [256]  EXTENSION front end only
     const uint32_t *w512_b;    // [256]
+    const int8_t *tie_delta;   // [kTieMax] DTW tie thresholds: T(g) = g*(g+2) + tie_delta[g] (sr_tables.h)
 };
 
 struct VadArgs {
@@ -73,6 +74,8 @@ struct DtwArgs {
     const uint32_t *tpl_orig;     // [K]
     uint32_t lds_u;               // utterances per k_dtw_lds workgroup (0 -> generic kernel), see dtw_lds_pick_u
     uint32_t lds_bytes;           // dynamic LDS of k_dtw_lds for that choice
+    const int8_t *tie_delta;      // DevTables::tie_delta
+    uint32_t tie_g;               // entries of it the workgroup stages in LDS (a multiple of 1024, <= kTieMax)
 };
 
 // get_mdl (DTW.C:217-296): P independent pairs
@@ -100,7 +103,7 @@ uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on th
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 // utterances per k_dtw_lds workgroup for K templates / max_frames rows (0 = use the generic kernel); tuning
 // override: environment variable SR_DTW_U, read when the template store is set
-uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes);
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer
 // generic complex 1024-point Q15 FFT, n arrays (cr4_fft_1024_stm32 semantics)

@@ -99,7 +99,7 @@ struct sr_engine {
     DevBuf<uint32_t> tplR;         // [rows][K] 32-byte rows (12 x s16 | norm | pad), templates ordered by length
     DevBuf<uint32_t> tpl_frames_s, tpl_orig;
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
-    uint32_t dtw_u = 0, dtw_lds = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
+    uint32_t dtw_u = 0, dtw_lds = 0, dtw_tie_g = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
     DevBuf<sr_vad_rec> s_vad;
@@ -198,6 +198,10 @@ int sr_build_tables(const sr_config *cfg, const sr_tables *out)
     if (out->tw_kr) std::memcpy(out->tw_kr, t.tw_kr.data(), t.tw_kr.size() * 2);
     if (out->tw_ki) std::memcpy(out->tw_ki, t.tw_ki.data(), t.tw_ki.size() * 2);
     if (out->log_thr) std::memcpy(out->log_thr, t.log_thr.data(), t.log_thr.size() * 4);
+    if (out->tie_delta) {
+        if (t.tie_delta.size() != (size_t)kTieMax) return fail(SR_ERR_BAD_CONFIG, "internal: DTW tie-threshold table does not fit 8 bits");
+        std::memcpy(out->tie_delta, t.tie_delta.data(), t.tie_delta.size());
+    }
     return SR_OK;
 }
 
@@ -255,12 +259,17 @@ int sr_create(const sr_config *cfg, sr_engine **out)
         const void *src;
         size_t bytes;
         size_t off;
-    } parts[12] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
+    } parts[13] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
                   {t.tri_odd.data(), t.tri_odd.size() * 2, 0}, {t.tri_cen.data(), t.tri_cen.size() * 2, 0},
                   {t.dct.data(), t.dct.size(), 0},             {t.tw_a.data(), t.tw_a.size() * 4, 0},
                   {t.tw_b.data(), t.tw_b.size() * 4, 0},       {t.log_thr.data(), t.log_thr.size() * 4, 0},
                   {t.w512_a.data(), t.w512_a.size() * 4, 0},   {t.w512_b.data(), t.w512_b.size() * 4, 0},
-                  {te32.data(), te32.size() * 4, 0},           {to32.data(), to32.size() * 4, 0}};
+                  {te32.data(), te32.size() * 4, 0},           {to32.data(), to32.size() * 4, 0},
+                  {t.tie_delta.data(), t.tie_delta.size(), 0}};
+    if (t.tie_delta.size() != (size_t)kTieMax) {
+        delete h;
+        return fail(SR_ERR_BAD_CONFIG, "internal: DTW tie-threshold table does not fit 8 bits");
+    }
     size_t total = 0;
     for (auto &p : parts) {
         p.off = total;
@@ -287,6 +296,7 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->dev.w512_b = (const uint32_t *)(base + parts[9].off);
     h->dev.tri_even32 = (const uint32_t *)(base + parts[10].off);
     h->dev.tri_odd32 = (const uint32_t *)(base + parts[11].off);
+    h->dev.tie_delta = (const int8_t *)(base + parts[12].off);
     *out = h;
     return SR_OK;
 }
@@ -379,6 +389,7 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
                 dst[6] = nrm;
             }
         }
+        if ((uint64_t)rows * K * 32 >= (1ull << 32)) fits = false;  // k_dtw_lds addresses the rows through a 32-bit byte offset
         if ((rc = n_tplR.reserve(rt.size()))) return rc;
         if ((rc = n_frames_s.reserve(K))) return rc;
         if ((rc = n_orig.reserve(K))) return rc;
@@ -412,8 +423,10 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     h->tpl_staged_ok = fits;
     {
         size_t lds = 0;
-        h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds) : 0;
+        uint32_t tie_g = 0;
+        h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds, &tie_g) : 0;
         h->dtw_lds = (uint32_t)lds;
+        h->dtw_tie_g = tie_g;
     }
     h->K = K;
     h->tpl_rows = rows;
@@ -616,6 +629,8 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.tpl_orig = h->tpl_orig.p;
     a.lds_u = h->dtw_u;
     a.lds_bytes = h->dtw_lds;
+    a.tie_delta = h->dev.tie_delta;
+    a.tie_g = h->dtw_tie_g;
     return a;
 }
 

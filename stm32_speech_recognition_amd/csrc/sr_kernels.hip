@@ -1590,6 +1590,8 @@ struct DtwLdsArgs {
     const uint32_t *tpl_frames_s;  // [K] frames, sorted order; 0 for invalid slots
     const uint32_t *tpl_orig;   // [K] original slot of sorted position
     uint32_t U;                 // utterances per workgroup
+    const int8_t *tie_delta;    // [tie_g] tie-threshold table (sr_tables.h), staged at the start of the dynamic LDS
+    uint32_t tie_g;             // entries staged: roots >= tie_g take the literal path
 };
 
 constexpr int kDtwMaxU = 16;
@@ -1654,6 +1656,7 @@ __device__ __forceinline__ int dot_rows_acc(const Row32 &a, const Row32 &b, int 
 // cost 8 cycles a pair (MI355X_MICROARCH.md, LDS table).
 typedef __attribute__((address_space(3))) const volatile u32x2 lds_cv_u32x2;
 typedef __attribute__((address_space(3))) const uint32_t lds_c_u32;
+typedef __attribute__((address_space(3))) const int8_t lds_c_i8;
 // LDS byte offset of a pointer into the workgroup's shared memory
 __device__ __forceinline__ uint32_t lds_offset(const void *p)
 {
@@ -1668,16 +1671,34 @@ __device__ __forceinline__ void lds_rows2(uint32_t row_off, uint32_t nrm_off, Ro
     r0 = row_from2(a0, a1, a2, np[0]);
     r1 = row_from2(b0, b1, b2, np[1]);
 }
+#ifdef SR_DTW_STATS
+// development build only: wave-steps in total / on the literal path, by reason (bracket, table range, lost lane)
+__device__ unsigned long long g_dtw_stats[8];
+extern "C" void sr_debug_dtw_stats(unsigned long long *out, int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dtw_stats), sizeof(g_dtw_stats));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dtw_stats), z, sizeof(z));
+    }
+}
+#endif
 __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32x2 smem2[];  // 8-byte typed: rows are read as ds_read_b64
-    __shared__ uint32_t s_n[kDtwMaxU];  // frames of the workgroup's utterances, 0 = skip
     const uint32_t U = a.U, R = a.d.max_frames, K = a.d.K;
-    // LDS image: 24-byte rows (3 x 8 bytes) + a separate array of squared norms.  Strides are padded so that
-    // lanes sitting on the same row of different utterances fall on different banks.
+    // LDS (all of it dynamic): [tie-threshold table, tie_g bytes][rows][norms][frame counts].  The table comes FIRST, at
+    // LDS address 0 (the kernel has no static LDS), so that a look-up is one ds_read_i8 whose address register is the
+    // root itself -- no VALU address arithmetic.
+    // Image of the utterances: 24-byte rows (3 x 8 bytes) + a separate array of squared norms.  Strides are padded so
+    // that lanes sitting on the same row of different utterances fall on different banks.
+    u32x2 *s_rows = smem2 + a.tie_g / 8;
     const uint32_t row_stride = dtw_lds_row_stride(R), nrm_stride = dtw_lds_nrm_stride(R);  // words
-    uint32_t *s_nrm = (uint32_t *)(smem2 + (size_t)U * (row_stride / 2));
+    uint32_t *s_nrm = (uint32_t *)(s_rows + (size_t)U * (row_stride / 2));
+    uint32_t *s_n = s_nrm + (size_t)U * nrm_stride + 8;  // frames of the workgroup's utterances, 0 = skip (+8 words: reload slack)
     const uint32_t tid = threadIdx.x, b0 = blockIdx.x * U;
+    for (uint32_t i = tid; i < a.tie_g / 16; i += blockDim.x) ((u32x4 *)smem2)[i] = ((const u32x4 *)a.tie_delta)[i];
 
     if (tid < U) {
         const uint32_t b = b0 + tid;
@@ -1695,7 +1716,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         if (!n) continue;
         const uint32_t rows = (n + 1 < R) ? n + 1 : R;
         const uint2 *src = (const uint2 *)(a.d.mfcc + (size_t)(b0 + u) * R * kCoef);
-        u32x2 *dst = smem2 + (size_t)u * (row_stride / 2);
+        u32x2 *dst = s_rows + (size_t)u * (row_stride / 2);
         for (uint32_t r = tid; r < rows; r += blockDim.x) {
             const uint2 q0 = src[3 * r], q1 = src[3 * r + 1], q2 = src[3 * r + 2];
             int nr = sdot2z(q0.x, q0.x);
@@ -1726,13 +1747,20 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         // and y < mdl_n < tpl_rows; for 1-frame sequences row 1 is the slack row the reference's do-while reads,
         // DTW.C:150-154); the reload after the last advance may touch one row past the utterance's image, which the
         // launch pads for.
-        uint32_t in_off = lds_offset(smem2 + (size_t)u * (row_stride / 2));  // LDS byte offsets of row x-1 and its norm
+        uint32_t in_off = lds_offset(s_rows + (size_t)u * (row_stride / 2));  // LDS byte offsets of row x-1 and its norm
         uint32_t nrm_off = lds_offset(s_nrm + (size_t)u * nrm_stride);
-        const u32x4 *tp = a.tplR + (size_t)ks * 2;
-        const uint32_t t_stride = K * 2;  // uint4 per template row level
-        Row32 cm = row_from(tp[0], tp[1]);
-        tp += t_stride;
-        Row32 nm = row_from(tp[0], tp[1]);
+        // template rows through a 32-bit byte offset from the (uniform) table base: advancing it is ONE add, and the
+        // loads take the base from SGPRs (a 64-bit per-lane pointer costs an add-with-carry pair per advance)
+        const char *tbase = (const char *)a.tplR;
+        uint32_t t_off = ks * 32u;
+        const uint32_t t_stride = K * 32u;  // bytes per template row level (K * 32 * rows < 2^32: checked at upload)
+        auto tpl_row = [&](uint32_t off) {
+            const u32x4 *q = (const u32x4 *)(tbase + off);
+            return row_from(q[0], q[1]);
+        };
+        Row32 cm = tpl_row(t_off);
+        t_off += t_stride;
+        Row32 nm = tpl_row(t_off);
         Row32 ci, ni;
         lds_rows2(in_off, nrm_off, ci, ni);
         uint32_t dis = (uint32_t)sqrt_rn_int((float)(uint32_t)dot_rows_acc(cm, ci, (int)(cm.w[6] + ci.w[6])));  // DTW.C:146
@@ -1757,31 +1785,30 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         do {
             // all three candidate squared distances, unconditionally: |m|^2 + |i|^2 + (-2m).i, the norm sum seeds
             // the dot2 accumulator (template rows are stored as -2m, see upload_templates)
-            const uint32_t d_up = (uint32_t)dot_rows_acc(nm, ci, (int)(nm.w[6] + ci.w[6]));  // (x, y+1):   get_dis(mdl+12, in)
+            // (x+1, y) first: it needs neither the template row that may still be in flight from the previous step's y advance
             const uint32_t d_rt = (uint32_t)dot_rows_acc(cm, ni, (int)(cm.w[6] + ni.w[6]));  // (x+1, y):   get_dis(mdl, in+12)
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t d_up = (uint32_t)dot_rows_acc(nm, ci, (int)(nm.w[6] + ci.w[6]));  // (x, y+1):   get_dis(mdl+12, in)
             const uint32_t d_dg = (uint32_t)dot_rows_acc(nm, ni, (int)(nm.w[6] + ni.w[6]));  // (x+1, y+1)
             bool in_up = (y1 < ubA1), in_rt = (lbB < y1) & (y1 <= ubB1), in_dg = (lbB <= y1) & (y1 < ubB1);
             // DTW.C:152-184 on the SQUARED candidates.  g(d) = (u32)sqrtf((float)d) is monotone, so the step cost is
             // g(min of the admissible candidates) -- one root instead of three -- and "min == right_up" / "min == up"
             // (the tie order of DTW.C:168-184) become g(q) == g(min)  <=>  q < T, T = first d with g(d) = g(min)+1.
-            // T is (g+1)^2 up to float rounding: every q < (g+1)^2 - mg ties and every q >= (g+1)^2 + mg does not, with
-            // mg = ((g+1)^2 >> 22) + 2 (checked for every g in tests/test_oracle.py); a candidate inside that narrow band,
-            // a root of 65535 or more (which includes "all three outside"), an unsafe bracket or a lost lane sends the wave
-            // down the literal three-root path.  The margin has to stay this tight: neighbouring frames are similar, so the
-            // three candidates lie close together and a constant margin of 18 already put 4 % of the wave-steps on the
-            // literal path (258: half of them).
-            // minimum over the admissible candidates: three v_min_u32 under the three admissibility masks (one v_mov + three
-            // v_min instead of three selects + two v_min; the masked-out candidates are never materialised)
+            // T is (g+1)^2 up to the rounding of (float)d; the exact value comes from a byte table in LDS (sr_tables.cpp:
+            // T(g) = g*(g+2) + tie_delta[g]), so there is no uncertain band around it.  A root outside the staged part of
+            // the table (which includes "all three outside"), an unsafe bracket or a lost lane sends the wave down the
+            // literal three-root path.
+            // minimum over the admissible candidates: one select and two v_min_u32 under the admissibility masks
+            // (the masked-out candidates are never materialised; 0xFFFFFFFF when none is admissible)
             const uint64_t m_up = __builtin_amdgcn_ballot_w64(y1 < ubA1),
                            m_rt = __builtin_amdgcn_ballot_w64(lbB < y1) & __builtin_amdgcn_ballot_w64(y1 <= ubB1),
                            m_dg = __builtin_amdgcn_ballot_w64(lbB <= y1) & __builtin_amdgcn_ballot_w64(y1 < ubB1);
             uint32_t m2;
             {
                 uint64_t ex;
-                asm volatile("v_mov_b32 %0, -1\n\t"
+                // m_dg is the result of an s_and_b64, i.e. SALU-written: no VALU-write -> VALU-read SGPR hazard on the select
+                asm volatile("v_cndmask_b32_e64 %0, -1, %5, %2\n\t"
                              "s_mov_b64 %1, exec\n\t"
-                             "s_and_b64 exec, %1, %2\n\t"
-                             "v_min_u32 %0, %0, %5\n\t"
                              "s_and_b64 exec, %1, %3\n\t"
                              "v_min_u32 %0, %0, %6\n\t"
                              "s_and_b64 exec, %1, %4\n\t"
@@ -1795,13 +1822,50 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             // compares, combined on the scalar unit): a bool OR-ed together and balloted afterwards costs two extra VALU ops
             const float s0 = __builtin_amdgcn_sqrtf((float)m2);
             uint32_t mn = (uint32_t)__int_as_float(__float_as_int(s0) + 1);  // floor(succ(s0)), see sqrt_floor_bracket
-            const uint32_t mm = mn + 1, M = umul24(mm, mm), mg = (M >> 22) + 2, lo_t = sub_sat(M, mg), hi_t = M + mg;
-            const bool tie_dg = in_dg & (d_dg < lo_t), tie_up = in_up & (d_up < lo_t);
-            const uint64_t unsafe = __builtin_amdgcn_ballot_w64(!(s0 > (float)mn)) | __builtin_amdgcn_ballot_w64(m2 >= 4294836225u) |
-                                    (m_dg & ~__builtin_amdgcn_ballot_w64(d_dg < lo_t) & __builtin_amdgcn_ballot_w64(d_dg < hi_t)) |
-                                    (m_up & ~__builtin_amdgcn_ballot_w64(d_up < lo_t) & __builtin_amdgcn_ballot_w64(d_up < hi_t)) | lost;
+            // T = first squared distance whose root is mn + 1 = mn*(mn + 2) + tie_delta[mn] (exact, sr_tables.cpp): a
+            // candidate q >= m2 has the root mn  <=>  q < T.  One byte from the LDS table (address register = the root,
+            // base = immediate offset), one add, one 24-bit multiply-add.  Roots >= tie_g -- which includes m2 = 0xFFFFFFFF,
+            // "all three outside" -- read past the table (out-of-range LDS reads return 0) and go down the literal path.
+            uint32_t T;
+            {
+                const int dl = *(lds_c_i8 *)(uintptr_t)mn;  // s_tie[mn]: the table sits at LDS address 0
+                const uint32_t mp2 = mn + 2;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(T) : "v"(mn), "v"(mp2), "v"(dl));
+            }
+            const bool tie_dg = in_dg & (d_dg < T), tie_up = in_up & (d_up < T);
+            // hard = the lanes that need the literal form; a failed bracket alone (about 5e-4 of the lane-steps, i.e. 3 % of the
+            // wave-steps) is settled exactly and cheaply inside the branch
+            const uint64_t hard = __builtin_amdgcn_ballot_w64(mn >= a.tie_g) | lost;
+            const uint64_t unsafe = __builtin_amdgcn_ballot_w64(!(s0 > (float)mn)) | hard;
             bool mv_diag = tie_dg, mv_up = tie_up & !tie_dg;
-            if (unsafe != 0ull) {  // wave-uniform; the literal form: dtw_limit on the three points, three roots, min, equality tests
+#ifdef SR_DTW_STATS
+            {
+                const uint64_t mb = __builtin_amdgcn_ballot_w64(!(s0 > (float)mn)), mr = __builtin_amdgcn_ballot_w64(mn >= a.tie_g),
+                               act = __builtin_amdgcn_ballot_w64(true);
+                if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)) == 0) {  // first active lane
+                    atomicAdd(&g_dtw_stats[0], 1ull);
+                    atomicAdd(&g_dtw_stats[5], (unsigned long long)__builtin_popcountll(act));
+                    if (unsafe) atomicAdd(&g_dtw_stats[1], 1ull);
+                    if (mb) atomicAdd(&g_dtw_stats[2], 1ull);
+                    if (mr) atomicAdd(&g_dtw_stats[3], 1ull);
+                    if (lost) atomicAdd(&g_dtw_stats[4], 1ull);
+                }
+            }
+#endif
+            if (unsafe != 0ull && hard == 0ull) {
+                // Only the bracket is in doubt: mn = floor(succ(s0)) is the root or one too many.  With k = mn the exact test
+                // g(d) < k  <=>  fmaf(-k, pred(k), (float)d) <= 0 settles it (k - h, h = half an ulp below k, is where sqrt
+                // rounds up to k; (k - h)^2 = k*pred(k) + h^2 and (float)d - k*pred(k) is a multiple of 4h^2, so the sign
+                // of the fused residual decides; checked against the C expression for every k and d around k^2 and on
+                // 2e8 random d, tests/test_oracle.py).  Lanes whose bracket was safe keep their mn.  Then the threshold and
+                // the two tie tests once more.
+                const float kf = (float)mn, f2 = (float)m2;
+                if (__builtin_fmaf(-kf, __int_as_float(__float_as_int(kf) - 1), f2) <= 0.0f) mn -= 1;
+                const int dl = *(lds_c_i8 *)(uintptr_t)mn;
+                const uint32_t T2 = mn * (mn + 2) + (uint32_t)dl;
+                mv_diag = in_dg & (d_dg < T2);
+                mv_up = in_up & (d_up < T2) & !mv_diag;
+            } else if (unsafe != 0ull) {  // wave-uniform; the literal form: dtw_limit on the three points, three roots, min, equality tests
                 const int x = xB - 1, y = y1 - 1;
                 in_up = !dtw_out(x, y1, X1, X2, (int)in_n, (int)mdl_n);
                 in_rt = !dtw_out(xB, y, X1, X2, (int)in_n, (int)mdl_n);
@@ -1818,6 +1882,15 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             }
             dis += mn;
             const bool adv_y = mv_diag || mv_up, adv_x = mv_diag || !mv_up;
+            // the y advance goes first: its template-row loads come from L2 and have the longest way to go before the next
+            // step's distances need them (the kernel runs close to where a wave's serial latency, not the issue port, sets
+            // the pace: 6 waves per SIMD, LDS-limited; this order alone is worth 6 % of the kernel's time)
+            if (adv_y) {
+                y1++;
+                copy_row(cm, nm);
+                asm volatile("v_add_u32 %0, %1, %0" : "+v"(t_off) : "s"(t_stride));
+                nm = tpl_row(t_off);
+            }
             if (adv_x) {
                 // in-place updates (tied asm operands): without them the compiler builds the new values in fresh
                 // registers and copies them into the loop-carried ones at the end of the block (three v_mov per step)
@@ -1838,12 +1911,6 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                     asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(lbB) : "v"(lb), "v"(la), "s"(m2x));
                 }
             }
-            if (adv_y) {
-                y1++;
-                copy_row(cm, nm);
-                tp += t_stride;
-                nm = row_from(tp[0], tp[1]);
-            }
             step++;
         } while (xB <= (int)in_n && y1 <= (int)mdl_n);  // DTW.C:188 (x < in && y < mdl)
         score = dis / step;
@@ -1851,25 +1918,42 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
     a.d.scores[(size_t)b * K + a.tpl_orig[ks]] = score;
 }
 
-// pick U: maximise resident lanes doing useful work (LDS 160 KiB/CU, 32 waves/CU, 1024 threads/workgroup)
-uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes)
+// pick U: maximise resident lanes doing useful work (LDS 160 KiB/CU, 32 waves/CU, 1024 threads/workgroup), then give
+// what is left of the workgroup's LDS share to the tie-threshold table (tie_g entries of one byte, a power of two).
+// gfx950 hands out LDS in granules of 1280 bytes (160 KiB / 128): three workgroups fit a CU only if each stays within
+// 42 granules = 53 760 bytes -- 20 bytes more and the third one silently does not (measured: mean waves per SIMD 5.0 -> 3.3),
+// although hipOccupancyMaxActiveBlocksPerMultiprocessor still reports 3.
+constexpr size_t kLdsGranule = 1280, kCuLds = 160 * 1024;
+__host__ __device__ inline size_t dtw_lds_fixed(uint32_t U, uint32_t max_frames)
+{
+    const size_t per_u = (size_t)(dtw_lds_row_stride(max_frames) + dtw_lds_nrm_stride(max_frames)) * 4;
+    // + 32: the reload after the last advance may read one row / two norms past the last utterance's image;
+    // + the frame counts of the U utterances
+    return U * per_u + 32 + ((4 * (size_t)U + 15) & ~(size_t)15);
+}
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g)
 {
     // The kernel is VALU-bound, so what counts is the fraction of lanes that carry a pair
     // (U*K / (64*waves)), as long as enough waves stay resident per CU to cover LDS/L2 latency.
-    const size_t per_u = (size_t)(dtw_lds_row_stride(max_frames) + dtw_lds_nrm_stride(max_frames)) * 4;
-    uint32_t best_u = 0;
+    const uint32_t kMinTie = 4096;  // below 4096 every threshold is the exact square: the least useful table
+    auto blocks_for = [](size_t lds) { return (uint32_t)(kCuLds / ((lds + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); };
+    uint32_t best_u = 0, best_g = 0;
     double best = 0;
-    const char *force = getenv("SR_DTW_U");  // tuning override
+    const char *force = getenv("SR_DTW_U");  // tuning overrides
+    const char *force_g = getenv("SR_DTW_TIE_G");
     for (uint32_t U = 1; U <= (uint32_t)kDtwMaxU; U++) {
         const uint64_t pairs = (uint64_t)U * K;
         if (pairs > 1024) break;
-        const size_t lds = U * per_u;
-        if (lds + 64 > 150 * 1024) break;
+        const size_t lds = dtw_lds_fixed(U, max_frames);
+        if (lds + kMinTie > 150 * 1024) break;
         const uint32_t waves = (uint32_t)((pairs + 63) / 64);
-        uint32_t blocks = (uint32_t)((160 * 1024) / (lds + 512));
+        uint32_t blocks = blocks_for(lds + kMinTie);
         if (blocks > 32 / waves) blocks = 32 / waves;
         if (blocks > 8) blocks = 8;
         if (blocks < 1) continue;
+        uint32_t g = kMinTie;  // the largest table that does not cost a resident workgroup
+        while (g < (uint32_t)kTieMax && blocks_for(lds + 2 * g) >= blocks) g *= 2;
+        if (force_g && atoi(force_g) >= (int)kMinTie && atoi(force_g) <= kTieMax) g = (uint32_t)atoi(force_g) & ~1023u;
         const double eff = (double)pairs / (64.0 * waves);
         const double resident = (double)(blocks * waves);
         double score = eff * (resident >= 24 ? 1.0 : resident / 24.0);
@@ -1877,9 +1961,11 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes)
         if (score > best + 1e-9) {
             best = score;
             best_u = U;
+            best_g = g;
         }
     }
-    if (best_u && lds_bytes) *lds_bytes = best_u * per_u + 64;  // + slack: the last reload may read one row / norm past the image
+    if (best_u && lds_bytes) *lds_bytes = dtw_lds_fixed(best_u, max_frames) + best_g;
+    if (tie_g) *tie_g = best_g;
     return best_u;
 }
 
@@ -1891,7 +1977,7 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
     const uint32_t U = a.tplR ? a.lds_u : 0;
     const size_t lds = a.lds_bytes;
     if (U) {
-        DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U};
+        DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U, a.tie_delta, a.tie_g};
         const uint32_t threads = (uint32_t)(((uint64_t)U * a.K + 63) / 64 * 64);
         hipLaunchKernelGGL(k_dtw_lds, dim3((a.B + U - 1) / U), dim3(threads), lds, s, la);
     } else {  // very long sequences / very many templates: generic global-memory walk

@@ -132,8 +132,31 @@ static void gen_log_thr(HostTables &t)
     }
 }
 
+// DTW.C:59 takes (u32)sqrtf((float)d) of a u32 sum of squares.  The root function g is monotone; the staged DTW kernel
+// decides the reference's tie order (DTW.C:168-184) on the squared distances against T(g) = first d whose root is g + 1,
+// found here with the host's own float conversion and sqrtf -- the very expression the reference evaluates (both are
+// IEEE-exact operations, so the table does not depend on the libm).
+static uint32_t root_u32(uint32_t d) { return (uint32_t)sqrtf((float)d); }
+
+static void gen_tie_delta(HostTables &t)
+{
+    t.tie_delta.assign(kTieMax, 1);
+    for (uint32_t g = 4095; g < (uint32_t)kTieMax; g++) {
+        const uint64_t M = (uint64_t)(g + 1) * (g + 1);  // <= 2^30
+        // g(M) >= g + 1 always ((float)M is within half a float spacing of M, far less than the 2g + 1 to the next
+        // square); walk down to the first d that still has the root g + 1.  (float)d is constant over runs of up to 64
+        // integers here, T(g) > g^2 + g, so the walk is short.
+        uint32_t d = (uint32_t)M;
+        while (root_u32(d - 1) >= g + 1) d--;
+        const int64_t delta = (int64_t)d - (int64_t)M + 1;
+        t.tie_delta[g] = (int8_t)delta;
+        if (delta < -128 || delta > 127) t.tie_delta.clear();  // cannot happen below 2^30 (half a float spacing <= 32)
+    }
+}
+
 void build_tables(HostTables &t, const FrontEnd &fe)
 {
+    gen_tie_delta(t);
     gen_hamm(t, fe);
     gen_tri(t, fe);
     gen_dct(t, fe);

@@ -16,6 +16,7 @@ constexpr int kMel = 24;        // tri_num, MFCC.H:12
 constexpr int kCoef = 12;       // mfcc_num, MFCC.H:13
 constexpr int kTwiddles = 1020; // 3 per butterfly, passes N = 16, 64, 256, 1024
 constexpr int kLogMax = 2218;   // floor(100*ln(2^32-1))
+constexpr int kTieMax = 32768;  // entries of the DTW tie-threshold table (roots below this take the one-root step)
 
 // The two front ends the kernels are built for: the reference's (ADC.H:7, VAD.H:5-8, MFCC.H:7-13) and the
 // 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
@@ -41,6 +42,11 @@ struct HostTables {
     std::vector<uint32_t> log_thr;
     // EXTENSION only: Q14 (cos, sin)(2*pi*k/512), k < 256, packed like the butterfly coefficients
     std::vector<uint32_t> w512_a, w512_b;
+    // DTW step (DTW.C:156-184): with g(d) = (u32)sqrtf((float)d) (DTW.C:59), T(g) = min{d : g(d) >= g + 1} is where the
+    // root steps from g to g + 1.  tie_delta[g] = T(g) - (g + 1)^2 + 1 for g < kTieMax, so that
+    // T(g) = g*(g + 2) + tie_delta[g] (one 24-bit multiply-add on the device).  Exact squares up to 2^24 convert to
+    // float exactly, so the entry is 1 for g < 4096; above, (float)d rounds d and T(g) falls a little short of (g + 1)^2.
+    std::vector<int8_t> tie_delta;
 };
 
 void build_tables(HostTables &t, const FrontEnd &fe);

@@ -64,7 +64,7 @@ def _vp(x):
 
 
 class _Tables(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("hamm", "tri_cen", "tri_even", "tri_odd", "dct", "tw_kr", "tw_ki", "log_thr")]
+    _fields_ = [(n, C.c_void_p) for n in ("hamm", "tri_cen", "tri_even", "tri_odd", "dct", "tw_kr", "tw_ki", "log_thr", "tie_delta")]
 
 
 def build_tables(**kw):
@@ -79,7 +79,7 @@ def build_tables(**kw):
     out = dict(hamm=np.zeros(frame_len, np.uint16), tri_cen=np.zeros(cfg.n_mel, np.uint16),
                tri_even=np.zeros(nb, np.uint16), tri_odd=np.zeros(nb, np.uint16),
                dct=np.zeros(cfg.n_coef * cfg.n_mel, np.int8), tw_kr=np.zeros(1020, np.int16),
-               tw_ki=np.zeros(1020, np.int16), log_thr=np.zeros(2220, np.uint32))
+               tw_ki=np.zeros(1020, np.int16), log_thr=np.zeros(2220, np.uint32), tie_delta=np.zeros(32768, np.int8))
     t = _Tables(**{k: v.ctypes.data_as(C.c_void_p) for k, v in out.items()})
     rc = L.sr_build_tables(C.byref(cfg), C.byref(t))
     if rc != 0:

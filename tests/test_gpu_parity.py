@@ -465,6 +465,39 @@ def test_dtw_ties_and_perfect_squares_match_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("scale", [600, 1500, 4000, 9000])
+def test_dtw_near_ties_at_large_roots_match_oracle(scale):
+    """every frame = one large base vector + a perturbation of a few units in two coefficients: the three squared
+    candidates of a step lie within tens of each other at 2^24 .. 2^30, where (float)d rounds and the step T(g) of the
+    root function falls short of (g+1)^2 -- the range the staged kernel's tie-threshold table covers (scale 9000 also
+    crosses its end, g = 32768, into the literal path)"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(scale)
+    maxf, K, B = 90, 40, 48
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(40, maxf, K).astype(np.uint32)
+    inf = rng.integers(45, 85, B).astype(np.uint32)
+    base_t = rng.integers(-scale, scale, (K, 1, 12))
+    base_i = rng.integers(-scale, scale, (B, 1, 12))
+    tm = np.repeat(base_t, maxf + 1, 1)
+    im = np.repeat(base_i, maxf, 1)
+    tm[:, :, 3] += rng.integers(-2, 3, (K, maxf + 1))
+    tm[:, :, 7] += rng.integers(-1, 2, (K, maxf + 1))
+    im[:, :, 3] += rng.integers(-2, 3, (B, maxf))
+    im[:, :, 9] += rng.integers(-1, 2, (B, maxf))
+    tm, im = tm.astype(np.int16), im.astype(np.int16)
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf)
+    sc, res = eng.dtw(im, inf)
+    pad = np.zeros((1, 12), np.int16)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
+                    dtype=np.uint32)
+    assert np.array_equal(sc, want)
+    ok = want != ol.DIS_ERR
+    assert ok.sum() > 500 and np.median(want[ok]) > 1.5 * scale
+    eng.close()
+
+
 def test_log_step_table_covers_all_steps(eng119, oracle):
     """MFCC.C:168 on the device = table of step positions built from the host's libm; cross-check the
     device path on filterbank-like magnitudes spanning 0 .. 2^32-1 via constant-spectrum frames is not

@@ -220,32 +220,59 @@ def test_dct_magic_multiplier_is_exact():
     assert int(np.log(float(2 ** 32 - 1)) * 100) == 2218 and (pw.max() << 14) < 2 ** 32 and M.max() < 2 ** 24
 
 
-def test_dtw_tie_thresholds_bracket_the_root_function(oracle):
-    """k_dtw_lds takes ONE root per step, g(min of the squared candidates), and decides the reference's tie order
-    (DTW.C:168-184) by comparing the other squared candidates with (g+1)^2 -/+ mg, mg = ((g+1)^2 >> 22) + 2.
-    That is exact iff g(q) <= g for every q < (g+1)^2 - mg and g(q) >= g+1 for every q >= (g+1)^2 + mg, with
-    g(d) = (u32)sqrtf((float)d) as in get_dis (DTW.C:59).  g is monotone, so the two boundary values per g suffice;
-    checked here for every g the kernel's fast path accepts (g <= 65534), with the C expression itself."""
+def _root(oracle, x):
+    """g(d) = (u32)sqrtf((float)d), DTW.C:59, evaluated by the oracle's C expression"""
     import ctypes as C
-    r = np.arange(0, 65535, dtype=np.int64)
-    M = (r + 1) * (r + 1)
-    mg = (M >> 22) + 2
-    lo, hi = np.maximum(M - mg, 0), M + mg
-    assert hi.max() < 2 ** 32
-    sel = lo > 0
-    x = np.concatenate([(lo[sel] - 1), hi]).astype(np.uint32)
+    x = np.ascontiguousarray(x, dtype=np.uint32)
     out = np.zeros(3 * len(x), np.uint32)
     oracle.L.sr_oracle_math_diag(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint32(len(x)))
-    g = out[1::3].astype(np.int64)
-    n = int(sel.sum())
-    assert (g[:n] <= r[sel]).all()      # largest value the kernel calls a tie really ties
-    assert (g[n:] >= r + 1).all()       # smallest value the kernel calls "greater" really is greater
-    # and monotonicity of g itself on a dense sample around every perfect square and across the 2^24 rounding knee
+    return out[1::3].astype(np.int64)
+
+
+def test_dtw_tie_threshold_table_is_exact(oracle):
+    """k_dtw_lds takes ONE root per step, g(min of the squared candidates), and decides the reference's tie order
+    (DTW.C:168-184) by comparing the other squared candidates with T(g) = first d whose root is g + 1, which the
+    product builds as a byte table: T(g) = g*(g+2) + tie_delta[g], g < 32768 (csrc/sr_tables.cpp, exported by the
+    host-only sr_build_tables).  g(d) = (u32)sqrtf((float)d) is monotone, so the table is exact iff
+    g(T - 1) == g and g(T) == g + 1 for every entry -- checked with the C expression itself."""
+    from stm32_speech_recognition_amd.engine import build_tables
+    dl = build_tables()["tie_delta"].astype(np.int64)
+    assert len(dl) == 32768 and (dl[:4096] == 1).all() and dl.min() >= -128
+    r = np.arange(len(dl), dtype=np.int64)
+    T = r * (r + 2) + dl
+    assert T.min() >= 1 and T.max() < 2 ** 32
+    assert np.array_equal(_root(oracle, T - 1), r)       # the largest value the kernel calls a tie really ties
+    assert np.array_equal(_root(oracle, T), r + 1)       # the smallest value it calls "greater" really is greater
+    # monotonicity of g itself on a dense sample around every 7th perfect square and across the 2^24 rounding knee
+    M = (np.arange(0, 65535, dtype=np.int64) + 1) ** 2
     xs = np.unique(np.clip(np.concatenate([M[::7, None] + np.arange(-3, 4)[None, :],
-                                           (2 ** 24 + np.arange(-2000, 2000))[None, :].repeat(1, 0)], axis=None), 0, 2 ** 32 - 1)).astype(np.uint32)
-    out = np.zeros(3 * len(xs), np.uint32)
-    oracle.L.sr_oracle_math_diag(xs.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint32(len(xs)))
-    assert (np.diff(out[1::3].astype(np.int64)) >= 0).all()
+                                           (2 ** 24 + np.arange(-2000, 2000))[None, :]], axis=None), 0, 2 ** 32 - 1))
+    assert (np.diff(_root(oracle, xs)) >= 0).all()
+
+
+def test_dtw_bracket_fixup_predicate_is_exact(oracle):
+    """When floor(succ(v_sqrt_f32(d))) may be one too many, k_dtw_lds settles it with
+    g(d) < k  <=>  fmaf(-k, pred(k), (float)d) <= 0   (k - h, h = half an ulp below k, is where sqrtf rounds up to k).
+    The fused residual is evaluated here in float64, where k*pred(k) (48 bits) is exact and the subtraction keeps the
+    sign; compared with the C expression for every k <= 65535 on the d around k^2 and on random d."""
+    k = np.arange(1, 65536, dtype=np.int64)
+    kf = k.astype(np.float32)
+    pf = (kf.view(np.int32) - 1).view(np.float32)
+    rng = np.random.default_rng(3)
+    for off in list(range(-40, 41, 1)) + [-600, -300, -129, 129, 300, 600]:
+        d = np.clip(k * k + off, 0, 2 ** 32 - 1)
+        f = d.astype(np.uint32).astype(np.float32)          # (float)d, round to nearest even like v_cvt_f32_u32 and C
+        test = (f.astype(np.float64) - kf.astype(np.float64) * pf.astype(np.float64)) <= 0
+        assert np.array_equal(test, _root(oracle, d) < k), off
+    d = rng.integers(0, 2 ** 32, 2_000_000, dtype=np.int64)
+    g = _root(oracle, d)
+    for kk in (g, g + 1):
+        sel = (kk >= 1) & (kk <= 65535)
+        kf = kk[sel].astype(np.float32)
+        pf = (kf.view(np.int32) - 1).view(np.float32)
+        f = d[sel].astype(np.uint32).astype(np.float32)
+        test = (f.astype(np.float64) - kf.astype(np.float64) * pf.astype(np.float64)) <= 0
+        assert np.array_equal(test, g[sel] < kk[sel])
 
 
 def store_to_templates(store, stride=4096, tmax=120, nc=12):
