@@ -113,6 +113,12 @@ typedef struct sr_tables {
     int8_t *tie_delta;  /* [32768]           DTW.C:59,156-184: T(g) = g*(g+2) + tie_delta[g] = min{d : (u32)sqrtf((float)d) >= g + 1} */
 } sr_tables;
 int sr_build_tables(const sr_config *cfg, const sr_tables *out);
+/* The log step table is built with the run-time host's libm `log` -- the expression MFCC.C:168 evaluates -- and compared with
+ * the positions the library ships (csrc/sr_log_thr_ref.inc: the libm the golden fixtures were generated with).  If they
+ * differ (a libm whose log is off in the last bit at an integer crossing of log(n)*100) the SHIPPED table is used, sr_create
+ * still succeeds, sr_last_error() holds a warning, and this returns the number of differing entries of the last
+ * sr_create / sr_build_tables of the process (0 = this host agrees). */
+int sr_log_table_mismatches(void);
 
 /* ------------------------------------------------------------------ template store
  * The firmware keeps templates as v_ftr_tag images in MCU flash at a 4 KiB stride

@@ -180,6 +180,21 @@ static int front_end_of(const sr_config *cfg, FrontEnd *fe)
     return SR_OK;
 }
 
+int sr_log_table_mismatches(void) { return log_table_mismatches(); }
+
+static void warn_log_table()
+{
+    if (const int bad = log_table_mismatches()) {
+        const std::string msg = "warning: this host's libm log() moves " + std::to_string(bad) +
+                                " of the 2219 steps of (u32)(log(n)*100) (MFCC.C:168) relative to the shipped table; the shipped "
+                                "positions are used, so results equal the golden fixtures', not this host's C path";
+        (void)fail(SR_OK, msg);
+        static bool once = false;
+        if (!once) std::fprintf(stderr, "sr_engine: %s\n", msg.c_str());
+        once = true;
+    }
+}
+
 // Host-only: the tables sr_create would upload for cfg, copied out for inspection (tests diff them against
 // MFCC_Arg.h:6-44 and cr4_fft_1024_stm32.s:285-629).  No device is touched.
 int sr_build_tables(const sr_config *cfg, const sr_tables *out)
@@ -190,6 +205,7 @@ int sr_build_tables(const sr_config *cfg, const sr_tables *out)
     if (rc) return rc;
     HostTables t;
     build_tables(t, fe);
+    warn_log_table();
     if (out->hamm) std::memcpy(out->hamm, t.hamm.data(), t.hamm.size() * 2);
     if (out->tri_cen) std::memcpy(out->tri_cen, t.tri_cen.data(), t.tri_cen.size() * 2);
     if (out->tri_even) std::memcpy(out->tri_even, t.tri_even.data(), t.tri_even.size() * 2);
@@ -252,6 +268,7 @@ int sr_create(const sr_config *cfg, sr_engine **out)
         if (x > 0) h->mfcc_grid_cap = (uint32_t)x;
     }
     build_tables(h->host, fe);
+    warn_log_table();
     // one blob, 16-byte aligned sub-tables
     const HostTables &t = h->host;
     std::vector<uint32_t> te32(t.tri_even.begin(), t.tri_even.end()), to32(t.tri_odd.begin(), t.tri_odd.end());

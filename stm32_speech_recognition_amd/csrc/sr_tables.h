@@ -50,5 +50,7 @@ struct HostTables {
 };
 
 void build_tables(HostTables &t, const FrontEnd &fe);
+// entries of the log step table where this host's libm disagreed with the shipped positions at the last build_tables
+int log_table_mismatches();
 
 }  // namespace sr
