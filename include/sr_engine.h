@@ -290,6 +290,10 @@ uint32_t *fft(int16_t *dat_buf, uint16_t buf_len);                              
 void cr4_fft_1024_stm32(void *pssOUT, void *pssIN, uint16_t Nbin);                               /* MFCC.C:12, .s:219 */
 uint32_t get_dis(int16_t *frm_ftr1, int16_t *frm_ftr2);                                          /* DTW.C:45 */
 uint8_t dtw_limit(uint16_t x, uint16_t y);                                                       /* DTW.C:76 */
+/* dtw(): models are cached by content on the device (up to 128 records, least recently used replaced); a model that is
+ * new to the cache costs one store upload, an input record that is new one launch against every cached model.  Callers
+ * whose model changes on every call (random pair sweeps) should use sr_dtw_batch.  Like every symbol of this section:
+ * one implicit engine, file-scope state, NOT thread-safe (as the reference: DTW.C:65-68). */
 uint32_t dtw(v_ftr_tag *ftr_in, v_ftr_tag *frt_mdl);                                             /* DTW.H:7, DTW.C:120 */
 uint8_t *spch_recg(uint16_t *v_dat, uint32_t *mtch_dis);                                         /* main.c:249 */
 void get_mean(int16_t *frm_ftr1, int16_t *frm_ftr2, int16_t *mean);                              /* DTW.C:195 */

@@ -76,6 +76,8 @@ struct ModelStore {
     std::vector<int16_t> rows;     // [n][kRecWords]
     std::vector<uint32_t> frames;  // [n]
     std::vector<uint64_t> hash;    // [n]
+    std::vector<uint64_t> used;    // [n] tick of the last hit (least recently used record is replaced when full)
+    uint64_t tick = 0;
     bool dirty = false;            // rows changed since the last upload
     uint64_t gen = 0;              // bumped whenever the store changes
     // scores of the last input record against every cached model
@@ -96,17 +98,26 @@ struct ModelStore {
     {
         const uint64_t hv = fnv(p, frm);
         for (size_t i = 0; i < frames.size(); i++)
-            if (hash[i] == hv && frames[i] == frm && std::memcmp(&rows[i * kRecWords], p, kRecWords * sizeof(int16_t)) == 0) return i;
-        if (frames.size() == kMaxCachedModels) {
-            rows.clear();
-            frames.clear();
-            hash.clear();
+            if (hash[i] == hv && frames[i] == frm && std::memcmp(&rows[i * kRecWords], p, kRecWords * sizeof(int16_t)) == 0) {
+                used[i] = ++tick;
+                return i;
+            }
+        dirty = true;
+        gen++;
+        if (frames.size() == kMaxCachedModels) {  // full: the least recently used record makes room (a cyclic scan over
+            size_t v = 0;                         // more slots than the store holds still misses every time, but 127
+            for (size_t i = 1; i < used.size(); i++)  // records stay valid instead of none)
+                if (used[i] < used[v]) v = i;
+            std::memcpy(&rows[v * kRecWords], p, kRecWords * sizeof(int16_t));
+            frames[v] = frm;
+            hash[v] = hv;
+            used[v] = ++tick;
+            return v;
         }
         rows.insert(rows.end(), p, p + kRecWords);
         frames.push_back(frm);
         hash.push_back(hv);
-        dirty = true;
-        gen++;
+        used.push_back(++tick);
         return frames.size() - 1;
     }
 } g_models;

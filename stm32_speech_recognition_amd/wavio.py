@@ -22,21 +22,34 @@ def pcm_to_adc(samples, sample_width):
 
 
 def resample_pcm(x, rate_in, rate_out, taps_per_phase=24):
-    """Polyphase FIR rate conversion of signed samples (float64 in, float64 out): zero-stuff by L, windowed-sinc
-    low-pass at min(rate_in, rate_out) / 2 (Kaiser, beta 8.6), keep every M-th sample; L / M = rate_out / rate_in
-    reduced.  Written with numpy only; the filter is linear-phase and its delay is removed."""
+    """Polyphase FIR rate conversion of signed samples (float64 in, float64 out), L / M = rate_out / rate_in reduced:
+    conceptually zero-stuff by L, low-pass at min(rate_in, rate_out) / 2 with a Kaiser-windowed sinc (beta 8.6), keep
+    every M-th sample.  Evaluated in polyphase form: output j sits at position k = half + j*M of the up-sampled stream,
+    only the taps h[k mod L + q*L] meet non-zero samples (x[k div L - q]), so an output costs about 2*taps_per_phase*
+    max(L, M)/L multiply-adds and nothing of size len(x)*L is ever built (44.1 kHz -> 8 kHz: 265 per output sample).
+    numpy only; the filter is linear-phase and its delay is removed."""
+    x = np.asarray(x, dtype=np.float64)
     if rate_in == rate_out:
-        return np.asarray(x, dtype=np.float64)
+        return x
     g = gcd(int(rate_in), int(rate_out))
     L, M = int(rate_out) // g, int(rate_in) // g
     half = taps_per_phase * max(L, M)
     n = np.arange(-half, half + 1)
     fc = 0.5 / max(L, M)                                        # cycles per sample at the rate rate_in * L
     h = 2 * fc * np.sinc(2 * fc * n) * np.kaiser(len(n), 8.6) * L
-    up = np.zeros(len(x) * L, dtype=np.float64)
-    up[::L] = np.asarray(x, dtype=np.float64)
-    y = np.convolve(up, h)[half:half + len(up)]
-    return y[::M]
+    Q = (2 * half) // L + 1                                     # taps that can meet a sample, per output
+    hp = np.concatenate([h, np.zeros(L)])                       # tap indices p + q*L may run up to 2*half + L - 1
+    xp = np.concatenate([np.zeros(Q), x, np.zeros(Q)])          # sample indices m0 - q run from -Q to len(x) + Q
+    n_out = (len(x) * L + M - 1) // M                           # = len(up[::M])
+    q = np.arange(Q)
+    y = np.empty(n_out, dtype=np.float64)
+    for j0 in range(0, n_out, 16384):
+        k = half + np.arange(j0, min(n_out, j0 + 16384)) * M
+        p, m0 = k % L, k // L
+        m = m0[:, None] - q[None, :]
+        m = np.where((m >= -Q) & (m < len(x) + Q), m, -Q) + Q   # outside the record: a zero of the padding
+        y[j0:j0 + len(k)] = np.einsum("jq,jq->j", hp[p[:, None] + q[None, :] * L], xp[m])
+    return y
 
 
 def wav_to_adc(path, expect_rate=None, resample=False):
