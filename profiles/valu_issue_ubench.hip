@@ -402,6 +402,101 @@ NEW64(K64)
 NEW32C(K32)
 NEW32D(K32)
 NEW32E(K32)
+// ---- round 3: run-length experiment.  Does the 2-cycle issue mode of the plain ops engage when the
+// 4-cycle ops are clustered, i.e. is there a run length N above which "add x N, perm x N" costs less than 4 cycles per
+// instruction?  Bodies of 128 / 512 / 2048 instructions; every wave runs the same code, so on a SIMD the W waves drift
+// through the runs independently (the hardware arbitrates between them every cycle).
+#define ADD8 X8(I_v_add_u32)
+#define PRM8 X8(I_v_perm_b32)
+#define DOT8 X8(I_v_dot2_i32_i16_acc)
+#define REP2(B) B B
+#define REP4(B) B B B B
+#define REP8(B) B B B B B B B B
+#define REP16(B) REP4(REP4(B))
+#define LIST_ID(S) S
+#define BODY_run8 REP8(ADD8 PRM8)
+#define BODY_run16 REP4(REP2(ADD8) REP2(PRM8))
+#define BODY_run32 REP2(REP4(ADD8) REP4(PRM8))
+#define BODY_run64 REP8(ADD8) REP8(PRM8)
+#define BODY_run256 REP4(REP8(ADD8)) REP4(REP8(PRM8))
+#define BODY_run1024 REP16(REP8(ADD8)) REP16(REP8(PRM8))
+#define BODY_run64_dot REP8(ADD8) REP8(DOT8)
+#define DEFKBODY(NAME) DEFK32B(NAME, BODY_##NAME)
+// same frame as DEFK32 with an explicit loop body
+#define DEFK32B(NAME, BODY)                                                                                     \
+    template <int LDSB>                                                                                         \
+    __global__ __launch_bounds__(256) void k_##NAME(Rec* out, uint32_t iters, uint32_t a, uint32_t b) {        \
+        __shared__ uint32_t pad[LDSB / 4];                                                                      \
+        uint32_t r0 = threadIdx.x + a, r1 = r0 * 3 + 1, r2 = r0 ^ 0x55, r3 = r0 + 77, r4 = r0 * 5, r5 = ~r0,    \
+                 r6 = r0 + b, r7 = r0 - b;                                                                      \
+        uint32_t va = a * 7 + (threadIdx.x & 3), vb = b | 0x01020304u;                                          \
+        if (iters == 0xFFFFFFFFu) pad[threadIdx.x] = a;                                                         \
+        __syncthreads();                                                                                        \
+        uint64_t R0 = memrealtime();                                                                            \
+        uint64_t T0 = memtime();                                                                                \
+        for (uint32_t i = 0; i < iters; ++i) {                                                                  \
+            asm volatile(BODY                                                                                   \
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)       \
+                         : "v"(va), "v"(vb)                                                                     \
+                         : "vcc", "scc");                                                                       \
+        }                                                                                                       \
+        uint64_t T1 = memtime();                                                                                \
+        uint64_t R1 = memrealtime();                                                                            \
+        uint32_t sink = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;                                                  \
+        if (iters == 0xFFFFFFFFu) sink ^= pad[(threadIdx.x * 7) & 255];                                         \
+        uint32_t hw, xc;                                                                                        \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                        \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc));                                       \
+        uint32_t lane_sink = __builtin_amdgcn_readfirstlane(sink);                                              \
+        if ((threadIdx.x & 63) == 0) {                                                                          \
+            Rec r;                                                                                              \
+            r.t0 = T0; r.t1 = T1; r.r0 = R0; r.r1 = R1; r.hw_id = hw; r.xcc_id = xc; r.sink = lane_sink; r.pad = 0; \
+            out[blockIdx.x * 4 + (threadIdx.x >> 6)] = r;                                                       \
+        }                                                                                                       \
+    }
+#define RUNS(X) X(run8) X(run16) X(run32) X(run64) X(run256) X(run1024) X(run64_dot)
+RUNS(DEFKBODY)
+// "wave A pure adds / wave B pure perms on the same SIMD": the wave slot (HW_ID[3:0]) picks the stream, so that with
+// W >= 2 waves on a SIMD half of them issue only plain adds and the other half only permutes (Rec.pad = 1 / 2)
+#define DEFKSPLIT(NAME, BODYA, BODYB)                                                                           \
+    template <int LDSB>                                                                                         \
+    __global__ __launch_bounds__(256) void k_##NAME(Rec* out, uint32_t iters, uint32_t a, uint32_t b) {        \
+        __shared__ uint32_t pad[LDSB / 4];                                                                      \
+        uint32_t r0 = threadIdx.x + a, r1 = r0 * 3 + 1, r2 = r0 ^ 0x55, r3 = r0 + 77, r4 = r0 * 5, r5 = ~r0,    \
+                 r6 = r0 + b, r7 = r0 - b;                                                                      \
+        uint32_t va = a * 7 + (threadIdx.x & 3), vb = b | 0x01020304u;                                          \
+        if (iters == 0xFFFFFFFFu) pad[threadIdx.x] = a;                                                         \
+        __syncthreads();                                                                                        \
+        uint32_t hw, xc;                                                                                        \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                        \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc));                                       \
+        const bool odd = __builtin_amdgcn_readfirstlane(hw) & 1;                                               \
+        uint64_t R0 = memrealtime();                                                                            \
+        uint64_t T0 = memtime();                                                                                \
+        if (odd) {                                                                                              \
+            for (uint32_t i = 0; i < iters; ++i)                                                                \
+                asm volatile(BODYB : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) \
+                             : "v"(va), "v"(vb) : "vcc", "scc");                                                \
+        } else {                                                                                                \
+            for (uint32_t i = 0; i < iters; ++i)                                                                \
+                asm volatile(BODYA : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) \
+                             : "v"(va), "v"(vb) : "vcc", "scc");                                                \
+        }                                                                                                       \
+        uint64_t T1 = memtime();                                                                                \
+        uint64_t R1 = memrealtime();                                                                            \
+        uint32_t sink = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;                                                  \
+        if (iters == 0xFFFFFFFFu) sink ^= pad[(threadIdx.x * 7) & 255];                                         \
+        uint32_t lane_sink = __builtin_amdgcn_readfirstlane(sink);                                              \
+        if ((threadIdx.x & 63) == 0) {                                                                          \
+            Rec r;                                                                                              \
+            r.t0 = T0; r.t1 = T1; r.r0 = R0; r.r1 = R1; r.hw_id = hw; r.xcc_id = xc; r.sink = lane_sink; r.pad = odd ? 2 : 1; \
+            out[blockIdx.x * 4 + (threadIdx.x >> 6)] = r;                                                       \
+        }                                                                                                       \
+    }
+DEFKSPLIT(split_add_perm, REP16(ADD8), REP16(PRM8))
+DEFKSPLIT(split_add_add, REP16(ADD8), REP16(ADD8))
+DEFKSPLIT(split_perm_perm, REP16(PRM8), REP16(PRM8))
+#define SPLITS(X) X(split_add_perm) X(split_add_add) X(split_perm_perm)
 DEFK32(v_cndmask_e64_vcc, X8, I_v_cndmask_e64_vcc, "s_mov_b32 vcc_lo, 0x55555555\ns_mov_b32 vcc_hi, 0x0f0f0f0f\n")
 DEFK32(v_cndmask_e64_s22, X8, I_v_cndmask_e64_s22, "s_mov_b32 s22, 0x55555555\ns_mov_b32 s23, 0x0f0f0f0f\n")
 // v_cndmask_b32 under different mask sources
@@ -480,7 +575,7 @@ struct Entry {
 #define L4 (40 * 1024)
 #define L8 (20 * 1024)
 #define ENT(NAME) {#NAME, 1, {k_##NAME<L1>, k_##NAME<L2>, k_##NAME<L4>, k_##NAME<L8>}},
-static Entry table[] = {ALL32(ENT) ALL64(ENT) NEW32(ENT) NEW64(ENT) NEW32C(ENT) NEW32D(ENT) NEW32E(ENT) CND(ENT)};
+static Entry table[] = {ALL32(ENT) ALL64(ENT) NEW32(ENT) NEW64(ENT) NEW32C(ENT) NEW32D(ENT) NEW32E(ENT) CND(ENT) RUNS(ENT) SPLITS(ENT)};
 
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "calib") return calib_main();
@@ -507,6 +602,8 @@ int main(int argc, char** argv) {
         if (only && std::string(e.name).find(only) == std::string::npos) continue;
         std::string nm = e.name;
         int per_slot = (nm.rfind("mix_", 0) == 0) ? 2 : (nm.rfind("mix", 0) == 0 ? nm[3] - '0' : 1);   // s_nop in the cmp pairs is not counted
+        if (nm == "run256") per_slot = 4;      // bodies longer than 128 instructions
+        if (nm == "run1024") per_slot = 16;
         uint64_t ninst = (uint64_t)iters * 128 * per_slot;
         printf("%s  {\"op\": \"%s\", \"insts_per_wave\": %llu", first ? "" : ",\n", e.name, (unsigned long long)ninst);
         first = false;
@@ -542,6 +639,13 @@ int main(int argc, char** argv) {
                 wmin = std::min(wmin, kv.second);
                 wmax = std::max(wmax, kv.second);
             }
+            std::vector<double> cycA, cycB;   // split kernels: waves of stream A (pad 1) / B (pad 2)
+            for (int i = 0; i < nw; ++i) {
+                if (h[i].pad == 1) cycA.push_back(cyc[i]);
+                if (h[i].pad == 2) cycB.push_back(cyc[i]);
+            }
+            std::sort(cycA.begin(), cycA.end());
+            std::sort(cycB.begin(), cycB.end());
             std::sort(cyc.begin(), cyc.end());
             std::sort(clk.begin(), clk.end());
             double med = cyc[nw / 2], mx = cyc[nw - 1], mn = cyc[0];
@@ -552,6 +656,12 @@ int main(int argc, char** argv) {
                    "\"kernel_ms_event\": %.4f, \"span_ms_realtime\": %.4f, \"ns_per_inst_per_simd_wall\": %.4f}",
                    W, med / ((double)ninst * W), mn / ((double)ninst * W), mx / ((double)ninst * W), ghz,
                    per_simd.size(), wmin, wmax, ms, span_ns * 1e-6, span_ns / ((double)ninst * W));
+            if (!cycA.empty() || !cycB.empty()) {
+                // per-stream: median wave time / instructions of ONE wave (a wave alone would show ~4.3)
+                printf(",\n   \"W%d_split\": {\"waves_A\": %zu, \"waves_B\": %zu, \"cyc_per_inst_per_wave_A\": %.3f, \"cyc_per_inst_per_wave_B\": %.3f}",
+                       W, cycA.size(), cycB.size(), cycA.empty() ? 0.0 : cycA[cycA.size() / 2] / (double)ninst,
+                       cycB.empty() ? 0.0 : cycB[cycB.size() / 2] / (double)ninst);
+            }
         }
         printf("}");
         fflush(stdout);
