@@ -23,6 +23,7 @@ struct DevTables {
     const uint32_t *w512_a;    // [256]  EXTENSION front end only
     const uint32_t *w512_b;    // [256]
     const int8_t *tie_delta;   // [kTieMax] DTW tie thresholds: T(g) = g*(g+2) + tie_delta[g] (sr_tables.h)
+    const uint32_t *hamm_pk;   // [frame_len / 2] hamm[2p] | hamm[2p+1] << 16 (k_mfcc_ext reads its window weights as pairs)
 };
 
 struct VadArgs {

@@ -272,17 +272,19 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     // one blob, 16-byte aligned sub-tables
     const HostTables &t = h->host;
     std::vector<uint32_t> te32(t.tri_even.begin(), t.tri_even.end()), to32(t.tri_odd.begin(), t.tri_odd.end());
+    std::vector<uint32_t> hpk(t.hamm.size() / 2);
+    for (size_t i = 0; i < hpk.size(); i++) hpk[i] = (uint32_t)t.hamm[2 * i] | ((uint32_t)t.hamm[2 * i + 1] << 16);
     struct Part {
         const void *src;
         size_t bytes;
         size_t off;
-    } parts[13] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
+    } parts[14] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
                   {t.tri_odd.data(), t.tri_odd.size() * 2, 0}, {t.tri_cen.data(), t.tri_cen.size() * 2, 0},
                   {t.dct.data(), t.dct.size(), 0},             {t.tw_a.data(), t.tw_a.size() * 4, 0},
                   {t.tw_b.data(), t.tw_b.size() * 4, 0},       {t.log_thr.data(), t.log_thr.size() * 4, 0},
                   {t.w512_a.data(), t.w512_a.size() * 4, 0},   {t.w512_b.data(), t.w512_b.size() * 4, 0},
                   {te32.data(), te32.size() * 4, 0},           {to32.data(), to32.size() * 4, 0},
-                  {t.tie_delta.data(), t.tie_delta.size(), 0}};
+                  {t.tie_delta.data(), t.tie_delta.size(), 0}, {hpk.data(), hpk.size() * 4, 0}};
     if (t.tie_delta.size() != (size_t)kTieMax) {
         delete h;
         return fail(SR_ERR_BAD_CONFIG, "internal: DTW tie-threshold table does not fit 8 bits");
@@ -314,6 +316,7 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->dev.tri_even32 = (const uint32_t *)(base + parts[10].off);
     h->dev.tri_odd32 = (const uint32_t *)(base + parts[11].off);
     h->dev.tie_delta = (const int8_t *)(base + parts[12].off);
+    h->dev.hamm_pk = (const uint32_t *)(base + parts[13].off);
     *out = h;
     return SR_OK;
 }

@@ -73,6 +73,7 @@ __device__ __forceinline__ float sqrt_rn_int(float f)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32_align2 __attribute__((aligned(2)));  // dword load at a 16-bit sample boundary
+typedef uint32_t u32x2_align2 __attribute__((ext_vector_type(2), aligned(2)));  // 8 bytes at a 16-bit sample boundary
 
 // ---- packed 16+16-bit helpers (VOP3P): one instruction works on the real and imaginary halves ----
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -682,6 +683,11 @@ __device__ __forceinline__ uint32_t row_scan_incl(uint32_t v)
     return v;
 }
 
+// Occupancy: 3 waves per SIMD (156 VGPRs, 50 KB of LDS per 4-wave workgroup).  Round 3 built the 4-waves-per-SIMD form the
+// round-2 review asked for (8-wave workgroups, one batch per item, lane constants re-read per batch: 126 VGPRs, 2 x 80 KB of
+// LDS per CU): mean waves per SIMD 2.74 -> 3.43, but the kernel alone stayed at 14.5 ms (its waits are the texture
+// addresser's, not latency that more waves would hide) and the pipelined step got SLOWER (51.5 vs 50.6 ms) because the
+// two workgroups took the whole LDS of a CU and the DTW workgroups of the other streams could no longer co-reside.
 __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs a)
 {
     using namespace ext;
@@ -702,7 +708,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
     const int base = rev2(gl >> 2) + 4 * rev2(gl & 3);
     uint32_t hp[10];  // Hamming weights of the lane's sample pairs (2*base + 32 t, +1)
 #pragma unroll
-    for (int t = 0; t < 10; t++) hp[t] = (uint32_t)a.t.hamm[2 * base + 32 * t] | ((uint32_t)a.t.hamm[2 * base + 32 * t + 1] << 16);
+    for (int t = 0; t < 10; t++) hp[t] = a.t.hamm_pk[base + 16 * t];
     // ---- constants of layout B: lane = (d0, d1), j = gl + 16*d2 + 64*d3 ----------------------------
     uint32_t k3[4][2];  // pass 3 (q = 16, coefficient block N = 64): index j & 15 = gl
     load_tw4(a.t, 12, gl, k3);
@@ -730,12 +736,13 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
         }
     }
     // filters h = gl, gl + 16, gl + 32 (< 40) of the lane's frame: bins [lo, hi) of poly-line h & 1 (MFCC.C:136-162)
-    int f_lo[3], f_hi[3];
+    uint32_t f_lohi[3];  // f_lo << 16 | f_hi (both <= 256)
 #pragma unroll
     for (int q = 0; q < 3; q++) {
         const int h = gl + 16 * q;
-        f_lo[q] = (h == 0 || h >= kMelE) ? 0 : (int)a.t.tri_cen[h - 1];
-        f_hi[q] = (h >= kMelE) ? 1 : (h == kMelE - 1) ? kBinsE : (int)a.t.tri_cen[h + 1];
+        const int lo = (h == 0 || h >= kMelE) ? 0 : (int)a.t.tri_cen[h - 1];
+        const int hi = (h >= kMelE) ? 1 : (h == kMelE - 1) ? kBinsE : (int)a.t.tri_cen[h + 1];
+        f_lohi[q] = ((uint32_t)lo << 16) | (uint32_t)hi;
     }
     __syncthreads();
 
@@ -743,32 +750,58 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
     // samples of the NEXT batch of four frames (same item, or the first batch of the next item that has frames) are
     // requested before the current batch is transformed, so the loads have a whole batch of arithmetic to land.
     struct Item {
-        const uint16_t *x0;  // first sample of the wave's first frame
+        const uint16_t *row;  // the capture buffer the item belongs to
+        int s0;               // sample index (in that buffer) of the wave's first frame
         int mid;
         uint32_t nf;         // frames this wave has in the item
     };
     auto item_info = [&](uint32_t it) {
-        Item r{nullptr, 0, 0u};
+        Item r{nullptr, 0, 0, 0u};
         if (it < a.n_items) {
             const uint32_t bb = it / a.tiles, tl = it - bb * a.tiles;
             const sr_vad_rec *rec = a.vad + bb;
             const uint32_t nfrm = rec->frm_num, ff = tl * kTile + w * kFpw;
             r.mid = (int)rec->atap.mid_val;
-            r.x0 = a.pcm + (uint64_t)bb * a.pcm_stride + rec->seg[0] + kHopE * (int)ff;
+            r.row = a.pcm + (uint64_t)bb * a.pcm_stride;
+            r.s0 = rec->seg[0] + kHopE * (int)ff;
             if (ff < nfrm) r.nf = (nfrm - ff < (uint32_t)kFpw) ? nfrm - ff : (uint32_t)kFpw;
         }
+        // wave-uniform (they depend on the wave's index only), but loaded through the vector memory path: moved to
+        // SGPRs so that the three records in flight do not occupy 12 VGPRs
+        const uint64_t xp = (uint64_t)(uintptr_t)r.row;
+        r.row = (const uint16_t *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xp >> 32)) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xp));
+        r.s0 = __builtin_amdgcn_readfirstlane(r.s0);
+        r.mid = __builtin_amdgcn_readfirstlane(r.mid);
+        r.nf = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.nf);
         return r;
     };
-    uint32_t qa[10], qb[10];  // pending sample pairs: x[i-1] | x[i] << 16 for i = 2*base + 32 t and i + 1
+    // pending samples x[i-2], x[i-1] (qa) and x[i], x[i+1] (qb) for i = 2*base + 32 t: one 8-byte load per pair, see fetch
+    uint32_t qa[10], qb[10];
     uint32_t q_item = 0xFFFFFFFFu, q_fb = 0;
     auto fetch = [&](const Item &it, uint32_t it_id, uint32_t fb) {
         const uint32_t fi = fb + (uint32_t)g;
-        const uint16_t *x = it.x0 + kHopE * (int)(fi < it.nf ? fi : it.nf - 1);  // groups past the last frame redo it
+        // Buffer loads: the (wave-uniform) capture buffer is a raw buffer resource in SGPRs, the lane's sample index one
+        // VGPR byte offset, the pair index t the instruction's immediate offset; the compiler emits buffer_load_dwordx2 for
+        // an 8-byte access of unknown alignment (for a global pointer it would split it into dwords).  A lane windows the
+        // samples i and i + 1, i = 2*base + 32 t, and needs x[i-1] for the pre-emphasis (MFCC.C:119): the 8 bytes fetched
+        // are x[i-2 .. i+1], which start on a 4-byte boundary whenever the segment starts on an even sample (segments from
+        // the VAD start on frame boundaries: always) -- the 2-byte-aligned form x[i-1 .. i+2] kept the texture addresser
+        // busy 55 % of the kernel.  x[i-2] of the very first pair may lie before the buffer (segment at sample 1): the
+        // offset is then negative = out of range for the resource, the load returns 0, and the value is never used.
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void *)it.row, 0, (int)(2 * (uint32_t)a.pcm_stride), 0x00027000);
+        const int off = 2 * (it.s0 - 2 + kHopE * (int)(fi < it.nf ? fi : it.nf - 1) + 2 * base);  // groups past the last frame redo it
 #pragma unroll
         for (int t = 0; t < 10; t++) {
-            const int i0 = 2 * base + 32 * t;
-            qa[t] = *(const u32_align2 *)(x + i0 - 1);
-            qb[t] = *(const u32_align2 *)(x + i0);
+#ifdef SR_EXT_NOLOAD  // timing experiment only: no sample traffic
+            qa[t] = 0x08000800u + (uint32_t)off;
+            qb[t] = 0x08010801u + (uint32_t)off;
+#else
+            const u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 64 * t, 0, 0);
+            qa[t] = q2.x;  // x[i-2] | x[i-1] << 16
+            qb[t] = q2.y;  // x[i]   | x[i+1] << 16
+#endif
         }
         q_item = it_id;
         q_fb = fb;
@@ -800,8 +833,8 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
             uint32_t ws[2][10];
 #pragma unroll
             for (int t = 0; t < 10; t++) {
-                const int c0 = (int)(pa[t] >> 16) - mid, p0 = (int)(pa[t] & 0xFFFFu) - mid;
-                const int c1 = (int)(pb[t] >> 16) - mid, p1 = (int)(pb[t] & 0xFFFFu) - mid;
+                const int p0 = (int)(pa[t] >> 16) - mid, c0 = (int)(pb[t] & 0xFFFFu) - mid;  // x[i-1], x[i]
+                const int c1 = (int)(pb[t] >> 16) - mid, p1 = c0;                              // x[i+1], x[i]
                 const int t0 = c0 - mul24(p0, 95) / 100, t1 = c1 - mul24(p1, 95) / 100;
                 ws[0][t] = (uint32_t)(mul24(t0, (int)(hp[t] & 0xFFFFu)) / 1000) & 0xFFFFu;
                 ws[1][t] = (uint32_t)(mul24(t1, (int)(hp[t] >> 16)) / 1000) & 0xFFFFu;
@@ -921,8 +954,8 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
                 const int h = gl + 16 * q;
                 if (h < kMelE) {
                     const uint32_t *P = xb + g * 512 + ((h & 1) ? 256 : 0), *X = moff + g * 32 + ((h & 1) ? 16 : 0);
-                    const int ih = f_hi[q] - 1, il = f_lo[q] - 1;
-                    const uint32_t hi = P[ih] + X[ih >> 4], lo = f_lo[q] ? P[il] + X[il >> 4] : 0u;
+                    const int f_lo = (int)(f_lohi[q] >> 16), ih = (int)(f_lohi[q] & 0xFFFFu) - 1, il = f_lo - 1;
+                    const uint32_t hi = P[ih] + X[ih >> 4], lo = f_lo ? P[il] + X[il >> 4] : 0u;
                     if (live) powb[fi * kMelEPad + h] = hi - lo;
                 }
             }
