@@ -162,6 +162,9 @@ def make_templates(eng, bank, Kt, n_words, rate, dev):
     return tm, tfr, rng
 
 
+FORCE_DIST = False  # test hook SR_BENCH_FORCE_DIST=1: initialise the process group and run the exchange even at N = 1
+
+
 def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     """K timed steps of one workload on this rank's GPU (barrier + synchronize on both sides, max over ranks), then an
     untimed isolated pass (whole batch as one chunk on one stream) for the per-kernel durations.  Returns a dict."""
@@ -178,9 +181,11 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     words = torch.from_numpy(rng.integers(0, n_words, world * B))[lo:hi]
     pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev, rate=rate)
     # N > 1: two output sets, so the all-gather of step i (RCCL stream) overlaps the kernels of step i+1
-    outs = [eng.alloc_outputs(B, dev, mfcc=True, vad=True) for _ in range(2 if world > 1 else 1)]
+    use_dist = dist is not None
+    outs = [eng.alloc_outputs(B, dev, mfcc=True, vad=True) for _ in range(2 if use_dist else 1)]
     out = outs[0]
-    xchg = du.ScoreExchange(world, [torch.empty(world * B, Kt, dtype=torch.int32, device=dev) for _ in outs]) if world > 1 else None
+    xchg = du.ScoreExchange(world, [torch.empty(world * B, Kt, dtype=torch.int32, device=dev) for _ in outs],
+                            force=FORCE_DIST) if use_dist else None
     n_step = [0]
 
     def step():
@@ -201,17 +206,17 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
         step()
     finish()
     eng.set_profiling(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     finish()  # every step's kernels AND its all-gather are complete
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    dt = du.max_over_ranks(dt, dev, world)
+    dt = du.max_over_ranks(dt, dev, 2 if (use_dist and world == 1) else world)
     stage = eng.stage_ms()  # hipEvent timings of the timed steps, each kernel on the stream it was launched on
     eng.set_profiling(False)
     # untimed extra: the same step as ONE chunk on one stream, for the per-kernel durations without overlap
@@ -273,6 +278,17 @@ def other_config(workload, B, Kt, steps, local_rank, cpu_n):
     return e
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when a communicator is created
+    (five lines: "RCCL version : ...", "HIP version", "ROCm version", "Hostname", "Librccl path"), and other libraries may do
+    the same: file descriptor 1 is pointed at stderr for the whole run and the JSON line goes out through a private
+    duplicate of the original stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -283,6 +299,7 @@ def main():
 
 
 def run_rank(args):
+    out_stream = claim_stdout()
     rank, local_rank, world = du.env_rank()
     # test hooks (tests/test_gpu_parity.py runs the N = 2 code path on a 1-GPU box): collective backend and a forced
     # device ordinal.  The driver never sets them: N > 1 means one rank per GPU over RCCL.
@@ -294,15 +311,24 @@ def run_rank(args):
     if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: device {local_rank} requested but {torch.cuda.device_count()} MI355X visible "
                          "(there is no CPU path; --gpus N needs N devices)")
+    global FORCE_DIST
+    FORCE_DIST = os.environ.get("SR_BENCH_FORCE_DIST") == "1"
     dist = None
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
+        if world == 1:  # test hook: a one-rank job still needs a rendezvous
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         du.init_process_group(backend, local_rank)
     torch.cuda.set_device(local_rank)
     B = args.batch
     m = measure(args.workload, B, args.templates, args.steps, args.warmup, rank, world, local_rank, dist)
     if rank == 0:
         line = headline(args, m, world, backend)
+        if FORCE_DIST:
+            line["config"]["parallelism"] += " -- TEST HOOK: process group and score exchange forced at N = 1"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], args.cpu_sample, m["eng_cfg"])
             if args.workload == "ref":
@@ -317,8 +343,9 @@ def run_rank(args):
             sc = args.other_scale
             line["other_configs"] = [other_config("ref", 4096 // sc, 10, args.other_steps, local_rank, cpu_n),
                                      other_config("ext", 65536 // sc, 500, args.other_steps, local_rank, cpu_n and 128)]
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        out_stream.write(json.dumps(line) + "\n")
+        out_stream.flush()
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -424,6 +451,7 @@ def run_single_process(args):
     and one stream per device, device-resident shards, and per step one grouped in-place ncclAllGather of the score
     matrix on the same streams (the exchange step of main.c:279-291's slot scan, for every utterance, on every GPU)."""
     from stm32_speech_recognition_amd.engine import MultiEngine
+    out_stream = claim_stdout()
     n, B = args.gpus, args.batch
     if args.workload != "ref":
         raise SystemExit("--launcher single runs the reference workload only")
@@ -488,7 +516,8 @@ def run_single_process(args):
     line["config"]["parallelism"] = f"utterance-sharded x{n}, RCCL all-gather of scores (single process, sr_multi)"
     if os.environ.get("SR_RCCL_LIBRARY"):
         line["config"]["parallelism"] += " -- TEST HOOK: collective library " + os.environ["SR_RCCL_LIBRARY"]
-    print(json.dumps(line), flush=True)
+    out_stream.write(json.dumps(line) + "\n")
+    out_stream.flush()
     me.close()
     return 0
 

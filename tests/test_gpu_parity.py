@@ -733,7 +733,7 @@ def _run_bench(extra, env_extra, timeout=900):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
                                                               "SR_BENCH_BACKEND", "SR_BENCH_DEVICE", "SR_RCCL_LIBRARY",
-                                                              "SR_MULTI_TEST_ALLOW_DUP")}
+                                                              "SR_MULTI_TEST_ALLOW_DUP", "SR_BENCH_FORCE_DIST")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True, text=True,
                        timeout=timeout, cwd=root)
@@ -753,6 +753,16 @@ def test_bench_plain_command_launches_its_own_ranks():
     assert j["config"]["batch_per_gpu"] == 4096 and "all-gather" in j["config"]["parallelism"]
     assert abs(j["value"] - 2 * 4096 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
     assert j["top1_word_accuracy"] == 1.0
+
+
+def test_bench_rccl_calls_with_one_rank():
+    """The rank-per-GPU path talks to RCCL through torch.distributed (init with device_id, barrier, asynchronous
+    all_gather_into_tensor with Work.wait, all_reduce MAX).  Two ranks cannot share a device on RCCL, so on this 1-GPU box
+    those very calls run with ONE rank (test hook SR_BENCH_FORCE_DIST): the N > 1 index arithmetic is covered by the gloo
+    runs, the RCCL call sequence by this one."""
+    j, _ = _run_bench(["--batch", "4096", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"],
+                      dict(SR_BENCH_FORCE_DIST="1"))
+    assert j["n_gpus"] == 1 and "TEST HOOK" in j["config"]["parallelism"] and j["top1_word_accuracy"] == 1.0
 
 
 def test_bench_plain_command_single_process_launcher():
