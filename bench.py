@@ -100,7 +100,17 @@ def self_launch(args):
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    import signal
     import threading
+
+    def stop_ranks(signum, frame):  # the job is being stopped from outside: take the ranks down with it (by PID)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        sys.exit(128 + signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, stop_ranks)
     lines = []
 
     def pump():
