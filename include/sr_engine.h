@@ -237,7 +237,7 @@ int sr_multi_recognize(sr_multi *m, const uint16_t *pcm, uint64_t pcm_stride, ui
 int sr_allgather_scores(void *nccl_comm, const uint32_t *d_scores, uint32_t *d_all, uint64_t count, void *stream);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
- * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 2048 utterances each, at most
+ * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 4096 utterances each, at most
  * SR_PIPE_MAX_CHUNKS = 12) and runs them on SR_PIPE_STREAMS = 3 (max 4) internal streams forked from / joined to the
  * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap (environment
  * variables read by sr_create; SR_PIPE_STREAMS=1 keeps everything on the caller's stream).  SR_MFCC_GRID overrides the

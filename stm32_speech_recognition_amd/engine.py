@@ -303,7 +303,7 @@ class Engine:
                                              C.c_void_p(stream)))
         return vad, mfcc
 
-    def set_pipeline(self, streams=3, min_chunk=2048, max_chunks=12):
+    def set_pipeline(self, streams=3, min_chunk=4096, max_chunks=12):
         """chunking of recognize_dev over the engine's internal streams (streams=1: one chunk, caller's stream)"""
         self._check(self.L.sr_set_pipeline(self.h, C.c_uint32(streams), C.c_uint32(min_chunk), C.c_uint32(max_chunks)))
 
