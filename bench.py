@@ -151,7 +151,7 @@ def self_launch(args):
     return rc
 
 
-def workload_setup(args, workload, Kt):
+def workload_setup(workload, Kt):
     """front-end configuration of a workload: (rate, engine config keywords, templates, vocabulary size)"""
     if workload == "ext":
         return 2, dict(fs=16000, nfft=512, n_mel=40), Kt or 500, min(100, Kt or 500)
@@ -178,7 +178,7 @@ FORCE_DIST = False  # test hook SR_BENCH_FORCE_DIST=1: initialise the process gr
 def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     """K timed steps of one workload on this rank's GPU (barrier + synchronize on both sides, max over ranks), then an
     untimed isolated pass (whole batch as one chunk on one stream) for the per-kernel durations.  Returns a dict."""
-    rate, eng_cfg, Kt, n_words = workload_setup(None, workload, Kt)
+    rate, eng_cfg, Kt, n_words = workload_setup(workload, Kt)
     dev = torch.device("cuda", local_rank)
     S = synth.buf_len_for(T, rate)
     eng = Engine(max_frames=MAX_FRAMES, device=local_rank, **eng_cfg)
@@ -470,7 +470,7 @@ def run_single_process(args):
         devs = [int(os.environ["SR_BENCH_DEVICE"])] * n
     if not torch.cuda.is_available() or max(devs) >= torch.cuda.device_count():
         raise SystemExit(f"--gpus {n} but {torch.cuda.device_count()} MI355X visible (there is no CPU path)")
-    rate, eng_cfg, Kt, n_words = workload_setup(None, "ref", args.templates)
+    rate, eng_cfg, Kt, n_words = workload_setup("ref", args.templates)
     S = synth.buf_len_for(T, rate)
     me = MultiEngine(devs, max_frames=MAX_FRAMES)
     bank = synth.word_bank(n_words)
