@@ -306,10 +306,14 @@ def test_full_size_batch_properties():
     eng.close()
 
 
-@pytest.mark.parametrize("seed,maxf,K", [(1, 257, 64), (2, 119, 101), (3, 37, 3), (4, 150, 1), (5, 64, 130), (6, 16, 17)])
+@pytest.mark.parametrize("seed,maxf,K", [(1, 257, 64), (2, 119, 101), (3, 37, 3), (4, 150, 1), (5, 64, 130), (6, 16, 17),
+                                          (7, 900, 20), (8, 2000, 12), (9, 5000, 5), (10, 6000, 4)])
 def test_random_shapes_match_oracle(seed, maxf, K):
     """seeded random engine shapes: frame cap, template count (incl. 1 and counts that leave DTW workgroups ragged),
-    batch size, utterance lengths that exceed the cap (MFCC fail), silent captures, erased slots, forced chunking"""
+    batch size, utterance lengths that exceed the cap (MFCC fail), silent captures, erased slots, forced chunking.
+    The large frame caps walk through the LDS budget of the staged DTW kernel: 900 / 2000 rows per utterance leave room for
+    5 / 2 utterances per workgroup and different tie-table sizes, 5000 for one (a 144 KB workgroup), 6000 for none
+    (generic kernel)."""
     from stm32_speech_recognition_amd import Engine
     from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch
     rng = np.random.default_rng(1000 + seed)
