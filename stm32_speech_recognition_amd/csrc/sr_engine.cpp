@@ -652,6 +652,7 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.lds_bytes = h->dtw_lds;
     a.tie_delta = h->dev.tie_delta;
     a.tie_g = h->dtw_tie_g;
+    a.lds_kc = dtw_lds_chunk(h->K);
     return a;
 }
 

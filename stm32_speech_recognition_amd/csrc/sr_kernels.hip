@@ -1625,6 +1625,7 @@ struct DtwLdsArgs {
     uint32_t U;                 // utterances per workgroup
     const int8_t *tie_delta;    // [tie_g] tie-threshold table (sr_tables.h), staged at the start of the dynamic LDS
     uint32_t tie_g;             // entries staged: roots >= tie_g take the literal path
+    uint32_t Kc;                // templates (ranks) per workgroup: blockIdx.y selects the chunk [y*Kc, (y+1)*Kc) of the K ranks
 };
 
 constexpr int kDtwMaxU = 16;
@@ -1766,9 +1767,11 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
     }
     __syncthreads();
 
-    if (tid >= U * K) return;
-    const uint32_t ks = tid / U, u = tid - ks * U, b = b0 + u;
-    if (b >= a.d.B) return;
+    // a store of more than 1024 / U templates is walked in chunks of Kc ranks (grid y): every chunk stages the same U
+    // utterances again (6 KB each from L2) and scores them against its slice of the length-sorted store
+    if (tid >= U * a.Kc) return;
+    const uint32_t ks = blockIdx.y * a.Kc + tid / U, u = tid % U, b = b0 + u;
+    if (b >= a.d.B || ks >= K) return;
     const uint32_t in_n = s_n[u], mdl_n = a.tpl_frames_s[ks];
     uint32_t score = SR_DIS_ERR;
     if (in_n && mdl_n && !(in_n > mdl_n * 2 || 2 * in_n < mdl_n)) {  // main.c:283, DTW.C:133-137
@@ -1964,8 +1967,17 @@ __host__ __device__ inline size_t dtw_lds_fixed(uint32_t U, uint32_t max_frames)
     // + the frame counts of the U utterances
     return U * per_u + 32 + ((4 * (size_t)U + 15) & ~(size_t)15);
 }
+// templates per workgroup for a store of K: all of them up to 512, otherwise the store is cut into equal chunks of at most
+// 512 ranks (a workgroup is at most 1024 lanes = U * Kc pairs, and U = 2 keeps two lanes on every template row)
+uint32_t dtw_lds_chunk(uint32_t K)
+{
+    if (K <= 512) return K;
+    const uint32_t chunks = (K + 511) / 512;
+    return (K + chunks - 1) / chunks;
+}
 uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g)
 {
+    K = dtw_lds_chunk(K);
     // The kernel is VALU-bound, so what counts is the fraction of lanes that carry a pair
     // (U*K / (64*waves)), as long as enough waves stay resident per CU to cover LDS/L2 latency.
     const uint32_t kMinTie = 4096;  // below 4096 every threshold is the exact square: the least useful table
@@ -2010,9 +2022,10 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
     const uint32_t U = a.tplR ? a.lds_u : 0;
     const size_t lds = a.lds_bytes;
     if (U) {
-        DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U, a.tie_delta, a.tie_g};
-        const uint32_t threads = (uint32_t)(((uint64_t)U * a.K + 63) / 64 * 64);
-        hipLaunchKernelGGL(k_dtw_lds, dim3((a.B + U - 1) / U), dim3(threads), lds, s, la);
+        const uint32_t Kc = a.lds_kc ? a.lds_kc : a.K, chunks = (a.K + Kc - 1) / Kc;
+        DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U, a.tie_delta, a.tie_g, Kc};
+        const uint32_t threads = (uint32_t)(((uint64_t)U * Kc + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_dtw_lds, dim3((a.B + U - 1) / U, chunks), dim3(threads), lds, s, la);
     } else {  // very long sequences / very many templates: generic global-memory walk
         hipLaunchKernelGGL(k_dtw, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
     }

@@ -502,6 +502,30 @@ def test_dtw_near_ties_at_large_roots_match_oracle(scale):
     eng.close()
 
 
+@pytest.mark.parametrize("K", [513, 700, 1500, 2050])
+def test_dtw_large_template_stores_match_oracle(K):
+    """more templates than one workgroup of the staged DTW kernel holds (1024 lanes): the length-sorted store is walked in
+    equal chunks of at most 512 ranks over the grid's second dimension; erased slots and length-gated pairs included"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(K)
+    maxf, B = 48, 9
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(1, maxf, K).astype(np.uint32)
+    tm = rng.integers(-2500, 2500, (K, maxf + 1, 12)).astype(np.int16)
+    valid = (rng.random(K) > 0.05).astype(np.uint8)
+    inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
+    im = rng.integers(-2500, 2500, (B, maxf, 12)).astype(np.int16)
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf, valid)
+    sc, res = eng.dtw(im, inf)
+    pad = np.zeros((1, 12), np.int16)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) if valid[k] else ol.DIS_ERR
+                      for k in range(K)] for b in range(B)], dtype=np.uint32)
+    assert np.array_equal(sc, want)
+    assert (want != ol.DIS_ERR).sum() > K and np.array_equal(res["min_dis"], want.min(1))
+    eng.close()
+
+
 def test_log_step_table_covers_all_steps(eng119, oracle):
     """MFCC.C:168 on the device = table of step positions built from the host's libm; cross-check the
     device path on filterbank-like magnitudes spanning 0 .. 2^32-1 via constant-spectrum frames is not
