@@ -56,22 +56,32 @@ __device__ __forceinline__ int mad24(int a, int b, int c)
     return r;
 }
 
-// sqrtf of an integer-valued float, correctly rounded: v_sqrt_f32 is within 1 ulp; one fused-residual
-// step against the two neighbouring floats picks the correctly rounded root (the compiler's own lowering
-// of sqrtf minus the denormal pre-scaling, which an integer-valued input never needs).  Bit-identical to
-// IEEE sqrtf, hence to the reference's sqrtf calls (MFCC.C:58, DTW.C:59).
+// sqrtf of an integer-valued float, correctly rounded -- bit-identical to IEEE sqrtf, hence to the reference's sqrtf calls
+// (MFCC.C:58, DTW.C:59).  Round 3: Markstein's fused correction of a reciprocal-root seed,
+//     y = v_rsq_f32(f)   s0 = f*y   h = 0.5*y   r = fma(-s0, s0, f)   s = fma(r, h, s0)
+// 6 issue slots (v_rsq counts twice) instead of 9 for v_sqrt_f32 + the residual test against both neighbouring floats, and
+// the two multiplies / two fmas of TWO roots pack into v_pk_mul_f32 / v_pk_fma_f32 (sqrt_rn_int2).  The seed f*y is off by
+// up to 2 ulp (wrong for 33 % of the inputs), the corrected value is the correctly rounded root for EVERY u32 input on
+// gfx950: proven by exhaustion, tests/exhaustive_math_sweep.py sweeps all 2^32 values through sr_math_diag against the
+// host's sqrtf (profiles/r03_exhaustive_math_sweep.txt), and every -m gpu run repeats a 2 M-value subset.  f = 0 gives
+// y = inf and s = NaN: every caller converts with v_cvt_u32_f32, for which NaN is 0 = (u32)sqrtf(0).
 __device__ __forceinline__ float sqrt_rn_int(float f)
 {
-    float s = __builtin_amdgcn_sqrtf(f);
-    const int si = __float_as_int(s);
-    const float s_dn = __int_as_float(si - 1), s_up = __int_as_float(si + 1);
-    const float vp = __builtin_fmaf(-s_dn, s, f), vs = __builtin_fmaf(-s_up, s, f);
-    s = (vp <= 0.0f) ? s_dn : s;
-    s = (vs > 0.0f) ? s_up : s;
-    return s;
+    const float y = __builtin_amdgcn_rsqf(f);
+    const float s0 = f * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-s0, s0, f);
+    return __builtin_fmaf(r, h, s0);
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two roots at once: the multiplies and fused corrections are packed f32 operations (one issue slot for both roots)
+__device__ __forceinline__ f32x2 sqrt_rn_int2(f32x2 f)
+{
+    const f32x2 y = {__builtin_amdgcn_rsqf(f.x), __builtin_amdgcn_rsqf(f.y)};
+    const f32x2 s0 = f * y, h = f32x2{0.5f, 0.5f} * y;
+    const f32x2 r = __builtin_elementwise_fma(-s0, s0, f);
+    return __builtin_elementwise_fma(r, h, s0);
+}
 typedef uint32_t u32_align2 __attribute__((aligned(2)));  // dword load at a 16-bit sample boundary
 typedef uint32_t u32x2_align2 __attribute__((ext_vector_type(2), aligned(2)));  // 8 bytes at a 16-bit sample boundary
 
@@ -577,9 +587,10 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                               k5[e3][1][1], k5[e3][2][0], k5[e3][2][1], k5[e3][3][0], k5[e3][3][1]);
                 // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
                 {
-                    const float s0 = sqrt_rn_int((float)sdot2z(u[e3][0], u[e3][0]));  // re*re + im*im from the packed word
-                    const float s1 = sqrt_rn_int((float)sdot2z(u[e3][1], u[e3][1]));
-                    const f32x2 m = f32x2{s0, s1} * f32x2{10.0f, 10.0f};  // both bins in one v_pk_mul_f32 (plain IEEE multiplies)
+                    // re*re + im*im from the packed word; both bins' roots and the x10 in packed f32 operations (plain IEEE
+                    // multiplies and fused multiply-adds, see sqrt_rn_int)
+                    const f32x2 m = sqrt_rn_int2(f32x2{(float)sdot2z(u[e3][0], u[e3][0]), (float)sdot2z(u[e3][1], u[e3][1])}) *
+                                    f32x2{10.0f, 10.0f};
                     const uint32_t m0 = (uint32_t)m.x, m1 = (uint32_t)m.y;  // < 2^19
                     buf[lane + 64 * e3] = umul24(m0, m0);
                     buf[lane + 64 * e3 + 256] = umul24(m1, m1);
@@ -899,6 +910,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const u32x4 wq = s_w512[c * 16 + gl];
+                float nrm[2];  // re^2 + im^2 of the two bins of this chunk; their roots are taken together (sqrt_rn_int2)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
                     const int m = 2 * c + h2, d2 = m & 3, d3 = m >> 2;
@@ -910,9 +922,12 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
                     const int t_re = (int)(((uint32_t)((int)(e << 16) >> 1)) + ((uint32_t)pr << 1));
                     const int t_im = (int)(((uint32_t)((int)(e & 0xFFFF0000u) >> 1)) + ((uint32_t)pi << 1));
                     const uint32_t xk = pk_hi16(t_re, t_im);  // (re, im) of X[k] as stored 16-bit values
-                    const uint32_t mag = (uint32_t)(sqrt_rn_int((float)sdot2z(xk, xk)) * 10.0f);
-                    xb[g * kEStride + gl + 20 * m] = mag * mag;  // bin k = gl + 16 m at k + 4*(k >> 4)
+                    nrm[h2] = (float)sdot2z(xk, xk);
                 }
+                const f32x2 mg = sqrt_rn_int2(f32x2{nrm[0], nrm[1]}) * f32x2{10.0f, 10.0f};
+                const uint32_t mag0 = (uint32_t)mg.x, mag1 = (uint32_t)mg.y;
+                xb[g * kEStride + gl + 20 * (2 * c)] = mag0 * mag0;  // bin k = gl + 16 m at k + 4*(k >> 4)
+                xb[g * kEStride + gl + 20 * (2 * c + 1)] = mag1 * mag1;
             }
             wave_sync();
             // ---- Mel filterbank via prefix sums (MFCC.C:136-162 at 40 filters / 256 bins): this lane owns the 16
@@ -2210,7 +2225,7 @@ void launch_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_
 // ------------------------------------------------------------------------------------------------
 // diagnostics: the three non-integer device functions on their own, so tests can sweep them directly
 //   out[3i+0] = (u32)(log((double)x)*100)                       MFCC.C:168   (step-function evaluation)
-//   out[3i+1] = (u32)sqrtf((float)x)                            DTW.C:59     (v_sqrt_f32 + fused-residual correction)
+//   out[3i+1] = (u32)sqrtf((float)x)                            DTW.C:59     (v_rsq_f32 seed + fused correction, sqrt_rn_int)
 //   out[3i+2] = (u32)(sqrtf((float)(s32)x)*10), x < 2^31        MFCC.C:56-58
 // ------------------------------------------------------------------------------------------------
 __global__ void k_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *log_thr)
