@@ -45,6 +45,13 @@ __device__ __forceinline__ int sdot2a(uint32_t a, uint32_t b, int c)
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// Pre-emphasis term of MFCC.C:119, (s32)p * hp_ratio with hp_ratio = 95/100 in integer arithmetic: p*95/100 truncated toward
+// zero, for |p| <= 65535 (u16 sample minus a u16 mid value; sr_mfcc_batch rejects a larger mid).  As three IEEE operations
+// -- convert, multiply by 0.95000005f (the float above 0.95), convert with truncation -- instead of a multiply and a
+// four-instruction signed division: p*95/100 is a multiple of 0.05, the relative error of the product stays below 2e-7,
+// i.e. below 0.012 in absolute terms, so truncation lands on the same integer; checked for every p of the domain with
+// the same IEEE operations in tests/test_oracle.py::test_preemphasis_float_form_is_exact.
+__device__ __forceinline__ int preemph95(int p) { return (int)((float)p * 0.95000005f); }
 // full-rate 24-bit multiplies where the operands provably fit (quarter-rate v_mul_lo_u32 otherwise)
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
@@ -555,7 +562,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 const int i = lane + 64 * k;
                 if (i < kFrameLen) {
                     const int cur = (int)(s_pp[k] >> 16) - mid, prv = (int)(s_pp[k] & 0xFFFFu) - mid;
-                    const int t = cur - mul24(prv, 95) / 100;
+                    const int t = cur - preemph95(prv);
                     // stored as the pass-1 output A >> 2 of the s16 sample (16-bit LDS store; the gather zero-extends)
                     xw[i] = (uint16_t)((int)(short)(mul24(t, hamm_r[k]) / 1000) >> 2);
                 }
@@ -846,7 +853,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
             for (int t = 0; t < 10; t++) {
                 const int p0 = (int)(pa[t] >> 16) - mid, c0 = (int)(pb[t] & 0xFFFFu) - mid;  // x[i-1], x[i]
                 const int c1 = (int)(pb[t] >> 16) - mid, p1 = c0;                              // x[i+1], x[i]
-                const int t0 = c0 - mul24(p0, 95) / 100, t1 = c1 - mul24(p1, 95) / 100;
+                const int t0 = c0 - preemph95(p0), t1 = c1 - preemph95(p1);
                 ws[0][t] = (uint32_t)(mul24(t0, (int)(hp[t] & 0xFFFFu)) / 1000) & 0xFFFFu;
                 ws[1][t] = (uint32_t)(mul24(t1, (int)(hp[t] >> 16)) / 1000) & 0xFFFFu;
             }

@@ -110,6 +110,18 @@ def test_product_tables_equal_oracle_tables(oracle):
     assert (f(thr[1:2219]) >= m).all() and (f(thr[1:2219] - 1) < m).all()
 
 
+def test_preemphasis_float_form_is_exact():
+    """MFCC.C:119 multiplies the previous sample by hp_ratio = 95/100 in integer arithmetic (p*95/100, truncated toward
+    zero).  The frame kernels evaluate it as (int)((float)p * 0.95000005f) -- convert, IEEE multiply, truncating convert --
+    for |p| <= 65535 (u16 sample - u16 mid).  Same IEEE operations here, whole domain."""
+    p = np.arange(-65535, 65536, dtype=np.int64)
+    want = (np.abs(p) * 95 // 100) * np.sign(p)                               # C division truncates toward zero
+    c = np.float32(0.95000005)
+    assert c == np.nextafter(np.float32(0.95), np.float32(1))
+    got = np.trunc((p.astype(np.float32) * c).astype(np.float32)).astype(np.int64)
+    assert np.array_equal(got, want)
+
+
 def test_log_step_table_is_checked_against_the_shipped_positions():
     """MFCC.C:168 on the device is a step function whose positions sr_create finds with the HOST's libm log.  A host whose
     log differs in the last bit at one of the 2219 integer crossings would silently shift a step relative to the golden
