@@ -80,6 +80,14 @@ __device__ __forceinline__ float sqrt_rn_int(float f)
     return __builtin_fmaf(r, h, s0);
 }
 
+// float -> u32 with the HARDWARE's semantics (v_cvt_u32_f32: truncation, NaN -> 0, saturation), stated as the instruction:
+// a C++ cast of NaN is undefined behaviour, and sqrt_rn_int(0) is NaN by design
+__device__ __forceinline__ uint32_t cvt_u32(float x)
+{
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two roots at once: the multiplies and fused corrections are packed f32 operations (one issue slot for both roots)
 __device__ __forceinline__ f32x2 sqrt_rn_int2(f32x2 f)
@@ -598,7 +606,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                     // multiplies and fused multiply-adds, see sqrt_rn_int)
                     const f32x2 m = sqrt_rn_int2(f32x2{(float)sdot2z(u[e3][0], u[e3][0]), (float)sdot2z(u[e3][1], u[e3][1])}) *
                                     f32x2{10.0f, 10.0f};
-                    const uint32_t m0 = (uint32_t)m.x, m1 = (uint32_t)m.y;  // < 2^19
+                    const uint32_t m0 = cvt_u32(m.x), m1 = cvt_u32(m.y);  // < 2^19
                     buf[lane + 64 * e3] = umul24(m0, m0);
                     buf[lane + 64 * e3 + 256] = umul24(m1, m1);
                 }
@@ -932,7 +940,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
                     nrm[h2] = (float)sdot2z(xk, xk);
                 }
                 const f32x2 mg = sqrt_rn_int2(f32x2{nrm[0], nrm[1]}) * f32x2{10.0f, 10.0f};
-                const uint32_t mag0 = (uint32_t)mg.x, mag1 = (uint32_t)mg.y;
+                const uint32_t mag0 = cvt_u32(mg.x), mag1 = cvt_u32(mg.y);
                 xb[g * kEStride + gl + 20 * (2 * c)] = mag0 * mag0;  // bin k = gl + 16 m at k + 4*(k >> 4)
                 xb[g * kEStride + gl + 20 * (2 * c + 1)] = mag1 * mag1;
             }
@@ -1454,7 +1462,7 @@ __device__ __forceinline__ uint32_t get_dis_dev(const Frame12 &fa, uint32_t na, 
 #pragma unroll
     for (int i = 0; i < 6; i++) dot = sdot2(fa.w[i], fb.w[i], dot);
     const uint32_t d = na + nb - 2u * (uint32_t)dot;
-    return (uint32_t)sqrtf((float)d);
+    return cvt_u32(sqrt_rn_int((float)d));
 }
 // dtw_limit (DTW.C:76-109); returns true when (x, y) is OUTSIDE the relaxed parallelogram
 __device__ __forceinline__ bool dtw_out(int x, int y, int X1, int X2, int in_n, int mdl_n)
@@ -1616,7 +1624,7 @@ __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
 __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
 {
     const uint32_t d = na + nb - 2u * (uint32_t)dot;
-    return (uint32_t)sqrt_rn_int((float)d);
+    return cvt_u32(sqrt_rn_int((float)d));
 }
 
 // floor(sqrtf(f)) by bracketing: v_sqrt_f32 is within 1 ulp, so the correctly rounded root is s0 or one of its two
@@ -1821,7 +1829,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         Row32 nm = tpl_row(t_off);
         Row32 ci, ni;
         lds_rows2(in_off, nrm_off, ci, ni);
-        uint32_t dis = (uint32_t)sqrt_rn_int((float)(uint32_t)dot_rows_acc(cm, ci, (int)(cm.w[6] + ci.w[6])));  // DTW.C:146
+        uint32_t dis = cvt_u32(sqrt_rn_int((float)(uint32_t)dot_rows_acc(cm, ci, (int)(cm.w[6] + ci.w[6]))));  // DTW.C:146
         // dtw_limit (DTW.C:76-109) as an interval test per column: (x', y') is inside  <=>  lb(x') <= y' <= ub(x')
         //   ub(x') = x' < X1 ? 2x'+1 : (x'+3-c1) >> 1      (negation of DTW.C:78-91; >> floors)
         //   lb(x') = x' < X2 ? x' >> 1 : 2x'+c2-3           (negation of DTW.C:93-106)
@@ -1928,9 +1936,9 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 in_up = !dtw_out(x, y1, X1, X2, (int)in_n, (int)mdl_n);
                 in_rt = !dtw_out(xB, y, X1, X2, (int)in_n, (int)mdl_n);
                 in_dg = !dtw_out(xB, y1, X1, X2, (int)in_n, (int)mdl_n);
-                const uint32_t up = in_up ? (uint32_t)sqrt_rn_int((float)d_up) : SR_DIS_ERR,
-                               right = in_rt ? (uint32_t)sqrt_rn_int((float)d_rt) : SR_DIS_ERR,
-                               diag = in_dg ? (uint32_t)sqrt_rn_int((float)d_dg) : SR_DIS_ERR;
+                const uint32_t up = in_up ? cvt_u32(sqrt_rn_int((float)d_up)) : SR_DIS_ERR,
+                               right = in_rt ? cvt_u32(sqrt_rn_int((float)d_rt)) : SR_DIS_ERR,
+                               diag = in_dg ? cvt_u32(sqrt_rn_int((float)d_dg)) : SR_DIS_ERR;
                 mn = diag;  // DTW.C:156-164
                 if (mn > right) mn = right;
                 if (mn > up) mn = up;
@@ -2245,10 +2253,10 @@ __global__ void k_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const
     // or a poison value if the fast path claims "safe" and disagrees (tests/exhaustive_math_sweep.py: all 2^32 inputs)
     {
         bool unsafe = false;
-        const uint32_t q = sqrt_floor_bracket(x, unsafe), e = (uint32_t)sqrt_rn_int((float)x);
+        const uint32_t q = sqrt_floor_bracket(x, unsafe), e = cvt_u32(sqrt_rn_int((float)x));
         out[3 * i + 1] = (unsafe || q == e) ? e : 0xDEAD0001u;
     }
-    out[3 * i + 2] = (uint32_t)(sqrt_rn_int((float)(int)(x & 0x7FFFFFFFu)) * 10.0f);
+    out[3 * i + 2] = cvt_u32(sqrt_rn_int((float)(int)(x & 0x7FFFFFFFu)) * 10.0f);
 }
 void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s)
 {
