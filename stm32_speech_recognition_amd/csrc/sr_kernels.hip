@@ -462,18 +462,19 @@ constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMelPad + 64;  // th
                                                                         // the last 64 words hold the odd filters' lane offsets
 
 // (u32)(log((double)n)*100), MFCC.C:168, as a step function (see sr_tables.cpp gen_log_thr).
+// v_log_f32 puts the estimate within one step of the answer for every u32 input (all 2^32 checked by
+// tests/exhaustive_math_sweep.py), so one look at the two neighbouring thresholds settles it.  Branch-free, one pair of
+// loads: the estimate is clamped to [1, kLogMax - 1] (still within one step of an answer in [0, kLogMax]), which also
+// takes care of both ends -- n = 0 (log2 = -inf -> clamped to 1, n < thr[1] = 2 -> 0 as on ARM softfp / x86-64, where the
+// UB cast of -inf gives 0) and the last step (its upper neighbour is the sentinel) -- and the two corrections are
+// compare + add/subtract-with-carry.  (The branching form the compiler made of the two-sided if cost two dependent
+// global loads with a wait each inside divergent control flow.)
 __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__restrict__ thr)
 {
-    if (n == 0) return 0;  // log(0) = -inf -> 0 (ARM softfp and x86-64 both give 0 for the UB cast)
-    int m = (int)(__log2f((float)n) * 69.31471806f);
-    m = m < 0 ? 0 : (m > kLogMax ? kLogMax : m);
-    // v_log_f32 puts the estimate within one step of the answer for every u32 input (all 2^32 checked by
-    // tests/exhaustive_math_sweep.py), so one look at the two neighbouring thresholds settles it
-    if (n < thr[m])
-        m -= 1;
-    else if (m < kLogMax && n >= thr[m + 1])
-        m += 1;
-    return (uint32_t)m;
+    const float e = __builtin_amdgcn_fmed3f(__log2f((float)n) * 69.31471806f, 1.0f, (float)(kLogMax - 1));
+    const int m = (int)e;
+    const uint32_t t0 = thr[m], t1 = thr[m + 1];
+    return (uint32_t)(m - (int)(n < t0) + (int)(n >= t1));
 }
 
 __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
