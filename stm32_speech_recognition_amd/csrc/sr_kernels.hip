@@ -652,13 +652,23 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         // (the pad word of each row goes through the log as well: harmless, never read)
         for (uint32_t t = lane; t < nf * kMelPad; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
         wave_sync();
-        for (uint32_t t = lane; t < nf * kCoef; t += 64) {
-            const uint32_t fi = t / kCoef, h = t - fi * kCoef;
-            int acc = 0;
+        // output t = fi*12 + h of the wave's tile goes to out[(f0 + fi)*12 + h] = out_w[t]: consecutive lanes store
+        // consecutive s16; fi = t / 12 by a 24-bit multiply (exact for t < 2^13), all index arithmetic in 32 bits
+        // (left to the compiler the 64-bit subscript became eight v_mad_u64_u32 per round)
+        {
+            int16_t *out_w = out + (size_t)f0 * kCoef;
 #pragma unroll
-            for (int i = 0; i < kMel; i++)
-                acc = mad24((int)__umulhi(powb[fi * kMelPad + i], s_dctM[h * kMelPad + i]), s_dctS[h * kMelPad + i], acc);
-            out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
+            for (uint32_t t = lane; t < (uint32_t)(kFramesPerWave * kCoef); t += 64) {
+                if (t < nf * kCoef) {
+                    const uint32_t fi = umul24(t, 10923u) >> 17, h = t - umul24(fi, (uint32_t)kCoef);
+                    const uint32_t *pw = powb + umul24(fi, (uint32_t)kMelPad), *dm = s_dctM + umul24(h, (uint32_t)kMelPad);
+                    const int *ds = s_dctS + umul24(h, (uint32_t)kMelPad);
+                    int acc = 0;
+#pragma unroll
+                    for (int i = 0; i < kMel; i++) acc = mad24((int)__umulhi(pw[i], dm[i]), ds[i], acc);
+                    out_w[t] = (int16_t)acc;
+                }
+            }
         }
         wave_sync();
         // rows >= frm_num of this tile are zeroed so that every row of the output is defined
@@ -994,13 +1004,20 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
         }
         for (uint32_t t = lane; t < nf * kMelEPad; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
         wave_sync();
-        for (uint32_t t = lane; t < nf * kCoef; t += 64) {
-            const uint32_t fi = t / kCoef, h = t - fi * kCoef;
-            int acc = 0;
+        {   // see k_mfcc: out[(f0 + fi)*12 + h] = out_w[t], 32-bit index arithmetic
+            int16_t *out_w = out + (size_t)f0 * kCoef;
 #pragma unroll
-            for (int i = 0; i < kMelE; i++)
-                acc = mad24((int)__umulhi(powb[fi * kMelEPad + i], s_dctM[h * kMelEPad + i]), s_dctS[h * kMelEPad + i], acc);
-            out[(uint64_t)(f0 + fi) * kCoef + h] = (int16_t)acc;
+            for (uint32_t t = lane; t < (uint32_t)(kFpw * kCoef); t += 64) {
+                if (t < nf * kCoef) {
+                    const uint32_t fi = umul24(t, 10923u) >> 17, h = t - umul24(fi, (uint32_t)kCoef);
+                    const uint32_t *pw = powb + umul24(fi, (uint32_t)kMelEPad), *dm = s_dctM + umul24(h, (uint32_t)kMelEPad);
+                    const int *ds = s_dctS + umul24(h, (uint32_t)kMelEPad);
+                    int acc = 0;
+#pragma unroll
+                    for (int i = 0; i < kMelE; i++) acc = mad24((int)__umulhi(pw[i], dm[i]), ds[i], acc);
+                    out_w[t] = (int16_t)acc;
+                }
+            }
         }
         wave_sync();
         {
