@@ -77,7 +77,7 @@ struct DtwArgs {
     uint32_t lds_bytes;           // dynamic LDS of k_dtw_lds for that choice
     const int8_t *tie_delta;      // DevTables::tie_delta
     uint32_t tie_g;               // entries of it the workgroup stages in LDS (a multiple of 1024, <= kTieMax)
-    uint32_t lds_kc;              // templates per k_dtw_lds workgroup (dtw_lds_chunk(K)); the store is walked in K / lds_kc chunks
+    uint32_t lds_kc;              // templates per k_dtw_lds workgroup (dtw_lds_pick_u); the store is walked in K / lds_kc chunks
 };
 
 // get_mdl (DTW.C:217-296): P independent pairs
@@ -105,8 +105,7 @@ uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on th
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 // utterances per k_dtw_lds workgroup for K templates / max_frames rows (0 = use the generic kernel); tuning
 // override: environment variable SR_DTW_U, read when the template store is set
-uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g);
-uint32_t dtw_lds_chunk(uint32_t K);  // templates per workgroup of the staged kernel (K itself up to 512)
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g, uint32_t *kc);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer
 // generic complex 1024-point Q15 FFT, n arrays (cr4_fft_1024_stm32 semantics)

@@ -99,7 +99,7 @@ struct sr_engine {
     DevBuf<uint32_t> tplR;         // [rows][K] 32-byte rows (12 x s16 | norm | pad), templates ordered by length
     DevBuf<uint32_t> tpl_frames_s, tpl_orig;
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
-    uint32_t dtw_u = 0, dtw_lds = 0, dtw_tie_g = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
+    uint32_t dtw_u = 0, dtw_lds = 0, dtw_tie_g = 0, dtw_kc = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
     DevBuf<sr_vad_rec> s_vad;
@@ -444,10 +444,15 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     h->tpl_staged_ok = fits;
     {
         size_t lds = 0;
-        uint32_t tie_g = 0;
-        h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds, &tie_g) : 0;
+        uint32_t tie_g = 0, kc = 0;
+        h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds, &tie_g, &kc) : 0;
         h->dtw_lds = (uint32_t)lds;
         h->dtw_tie_g = tie_g;
+        h->dtw_kc = kc;
+        if (const char *dbg = getenv("SR_DTW_DEBUG"))
+            if (dbg[0] == '1')
+                std::fprintf(stderr, "sr_engine: k_dtw_lds geometry for K = %u, %u rows: U = %u, Kc = %u, tie table %u, LDS %zu bytes\n", K,
+                             h->cfg.max_frames, h->dtw_u, kc, tie_g, lds);
     }
     h->K = K;
     h->tpl_rows = rows;
@@ -652,7 +657,7 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.lds_bytes = h->dtw_lds;
     a.tie_delta = h->dev.tie_delta;
     a.tie_g = h->dtw_tie_g;
-    a.lds_kc = dtw_lds_chunk(h->K);
+    a.lds_kc = h->dtw_kc;
     return a;
 }
 

@@ -2015,28 +2015,28 @@ __host__ __device__ inline size_t dtw_lds_fixed(uint32_t U, uint32_t max_frames)
     // + the frame counts of the U utterances
     return U * per_u + 32 + ((4 * (size_t)U + 15) & ~(size_t)15);
 }
-// templates per workgroup for a store of K: all of them up to 512, otherwise the store is cut into equal chunks of at most
-// 512 ranks (a workgroup is at most 1024 lanes = U * Kc pairs, and U = 2 keeps two lanes on every template row)
-uint32_t dtw_lds_chunk(uint32_t K)
+// Geometry of a k_dtw_lds launch for a store of K templates and max_frames rows per utterance: U utterances and Kc
+// templates (ranks) per workgroup (U * Kc <= 1024 lanes; the store is walked in ceil(K / Kc) equal chunks over grid.y), the
+// LDS bytes, and the tie-table entries that fit beside the utterances.  What counts: the fraction of lanes that carry a pair,
+// enough resident waves to cover the LDS / L2 latency of the walk, and -- measured at K = 500 -- how many lanes share a
+// template row: the texture addresser is the limit there, and U = 6 x 167 templates runs 12 % faster than U = 2 x 500
+// (30.2 vs 34.3 ms per 65 536 utterances), while U = 10 x 100 (one workgroup per CU) loses 10 %.
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g, uint32_t *kc_out)
 {
-    if (K <= 512) return K;
-    const uint32_t chunks = (K + 511) / 512;
-    return (K + chunks - 1) / chunks;
-}
-uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g)
-{
-    K = dtw_lds_chunk(K);
-    // The kernel is VALU-bound, so what counts is the fraction of lanes that carry a pair
-    // (U*K / (64*waves)), as long as enough waves stay resident per CU to cover LDS/L2 latency.
     const uint32_t kMinTie = 4096;  // below 4096 every threshold is the exact square: the least useful table
     auto blocks_for = [](size_t lds) { return (uint32_t)(kCuLds / ((lds + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); };
-    uint32_t best_u = 0, best_g = 0;
+    uint32_t best_u = 0, best_g = 0, best_kc = 0;
     double best = 0;
     const char *force = getenv("SR_DTW_U");  // tuning overrides
     const char *force_g = getenv("SR_DTW_TIE_G");
+    const char *force_kc = getenv("SR_DTW_KC");
     for (uint32_t U = 1; U <= (uint32_t)kDtwMaxU; U++) {
-        const uint64_t pairs = (uint64_t)U * K;
-        if (pairs > 1024) break;
+        uint32_t kc = K < 1024u / U ? K : 1024u / U;  // lanes of a workgroup
+        if (force_kc && atoi(force_kc) >= 1 && (uint32_t)atoi(force_kc) < kc) kc = (uint32_t)atoi(force_kc);
+        if (!kc) break;
+        const uint32_t chunks = (K + kc - 1) / kc;
+        kc = (K + chunks - 1) / chunks;             // equal chunks
+        const uint64_t pairs = (uint64_t)U * kc;
         const size_t lds = dtw_lds_fixed(U, max_frames);
         if (lds + kMinTie > 150 * 1024) break;
         const uint32_t waves = (uint32_t)((pairs + 63) / 64);
@@ -2047,18 +2047,25 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint
         uint32_t g = kMinTie;  // the largest table that does not cost a resident workgroup
         while (g < (uint32_t)kTieMax && blocks_for(lds + 2 * g) >= blocks) g *= 2;
         if (force_g && atoi(force_g) >= (int)kMinTie && atoi(force_g) <= kTieMax) g = (uint32_t)atoi(force_g) & ~1023u;
-        const double eff = (double)pairs / (64.0 * waves);
+        const double eff = (double)K / ((double)chunks * 64.0 * waves / U);  // lanes that carry a pair, over all chunks
         const double resident = (double)(blocks * waves);
-        double score = eff * (resident >= 24 ? 1.0 : resident / 24.0);
+        // lanes per template row: worth more the larger the store (at K = 100 five utterances x 100 templates in three
+        // workgroups per CU beat eight x 100 in two, 6.4 vs 6.6 ms; at K = 500 eight x 125 beat two x 500, 31 vs 34 ms);
+        // every further chunk stages the utterances once more
+        const double w = 0.5 * (K >= 400 ? 1.0 : K / 400.0);
+        const double share = (1.0 - w / U) * (1.0 - 0.005 * (chunks - 1));
+        double score = eff * (resident >= 24 ? 1.0 : resident / 24.0) * share;
         if (force && (uint32_t)atoi(force) == U) score = 100.0;
         if (score > best + 1e-9) {
             best = score;
             best_u = U;
             best_g = g;
+            best_kc = kc;
         }
     }
     if (best_u && lds_bytes) *lds_bytes = dtw_lds_fixed(best_u, max_frames) + best_g;
     if (tie_g) *tie_g = best_g;
+    if (kc_out) *kc_out = best_kc;
     return best_u;
 }
 
@@ -2070,7 +2077,7 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
     const uint32_t U = a.tplR ? a.lds_u : 0;
     const size_t lds = a.lds_bytes;
     if (U) {
-        const uint32_t Kc = a.lds_kc ? a.lds_kc : a.K, chunks = (a.K + Kc - 1) / Kc;
+        const uint32_t Kc = (a.lds_kc && a.lds_kc < a.K) ? a.lds_kc : a.K, chunks = (a.K + Kc - 1) / Kc;
         DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U, a.tie_delta, a.tie_g, Kc};
         const uint32_t threads = (uint32_t)(((uint64_t)U * Kc + 63) / 64 * 64);
         hipLaunchKernelGGL(k_dtw_lds, dim3((a.B + U - 1) / U, chunks), dim3(threads), lds, s, la);
