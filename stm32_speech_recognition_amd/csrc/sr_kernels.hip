@@ -1818,6 +1818,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
     // a store of more than 1024 / U templates is walked in chunks of Kc ranks (grid y): every chunk stages the same U
     // utterances again (6 KB each from L2) and scores them against its slice of the length-sorted store
     if (tid >= U * a.Kc) return;
+    // (rank major, utterance minor; the other order -- a wave = consecutive ranks of one utterance -- is slower: 6.52 vs 6.31 ms)
     const uint32_t ks = blockIdx.y * a.Kc + tid / U, u = tid % U, b = b0 + u;
     if (b >= a.d.B || ks >= K) return;
     const uint32_t in_n = s_n[u], mdl_n = a.tpl_frames_s[ks];
