@@ -2054,7 +2054,9 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint
         // workgroups per CU beat eight x 100 in two, 6.4 vs 6.6 ms; at K = 500 eight x 125 beat two x 500, 31 vs 34 ms);
         // every further chunk stages the utterances once more
         const double w = 0.5 * (K >= 400 ? 1.0 : K / 400.0);
-        const double share = (1.0 - w / U) * (1.0 - 0.005 * (chunks - 1));
+        // a table that ends at a root of 8192 (4096) sends squared distances above 6.7e7 (1.7e7) down the literal path
+        const double cover = g >= 16384 ? 1.0 : g >= 8192 ? 0.98 : 0.9;
+        const double share = (1.0 - w / U) * (1.0 - 0.005 * (chunks - 1)) * cover;
         double score = eff * (resident >= 24 ? 1.0 : resident / 24.0) * share;
         if (force && (uint32_t)atoi(force) == U) score = 100.0;
         if (score > best + 1e-9) {
