@@ -252,6 +252,12 @@ int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
 int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);
 
+/* diagnostics, host-only (touches no device): the launch geometry the staged DTW kernel would use for a store of n_templates
+ * and a frame cap of max_frames: out[0] = utterances per workgroup (0 = generic kernel), out[1] = templates per workgroup (the
+ * store is walked in ceil(n_templates / out[1]) chunks), out[2] = tie-threshold table entries staged in LDS, out[3] = LDS bytes
+ * per workgroup, out[4] = workgroups that fit one CU's 160 KiB at gfx950's allocation granule of 1280 bytes. */
+int sr_dtw_geometry(uint32_t n_templates, uint32_t max_frames, uint32_t out[5]);
+
 /* diagnostics: the path's non-integer device functions swept directly:
  * out[3i] = (u32)(log((double)x)*100) (MFCC.C:168), out[3i+1] = (u32)sqrtf((float)x) (DTW.C:59),
  * out[3i+2] = (u32)(sqrtf((float)(s32)(x & 0x7fffffff))*10) (MFCC.C:56-58) */

@@ -183,6 +183,20 @@ static int front_end_of(const sr_config *cfg, FrontEnd *fe)
 
 int sr_log_table_mismatches(void) { return log_table_mismatches(); }
 
+int sr_dtw_geometry(uint32_t n_templates, uint32_t max_frames, uint32_t out[5])
+{
+    if (!out || !n_templates || max_frames < 2 || max_frames > 16383) return fail(SR_ERR_BAD_ARG, "null / zero argument");
+    size_t lds = 0;
+    uint32_t tie_g = 0, kc = 0;
+    const uint32_t U = dtw_lds_pick_u(n_templates, max_frames, &lds, &tie_g, &kc);
+    out[0] = U;
+    out[1] = U ? kc : 0;
+    out[2] = U ? tie_g : 0;
+    out[3] = U ? (uint32_t)lds : 0;
+    out[4] = U ? (uint32_t)((160u * 1024u) / ((lds + 1279) / 1280 * 1280)) : 0;
+    return SR_OK;
+}
+
 static void warn_log_table()
 {
     if (const int bad = log_table_mismatches()) {

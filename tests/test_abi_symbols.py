@@ -65,3 +65,30 @@ def test_c_demo_compiles_and_links_as_plain_c(tmp_path):
     engine.load_library()
     build_c_demo(str(tmp_path / "spch_recg_demo"))
     build_c_demo(str(tmp_path / "multi_gpu_demo"), "multi_gpu_demo.c")
+
+
+def test_dtw_launch_geometry_respects_the_lds_budget():
+    """Host-only sr_dtw_geometry: the staged DTW kernel's workgroup shape for any store size / frame cap.  gfx950 hands out
+    LDS in granules of 1280 bytes; in round 3 a workgroup of 53 780 bytes (43 granules instead of 42) silently cost the third
+    workgroup per CU.  Invariants: U * Kc <= 1024 lanes, the workgroups the scorer counted on really fit 160 KiB at the
+    granule, the table is a power of two >= 4096; and the benchmark shapes keep their measured optima."""
+    import ctypes as C
+    from stm32_speech_recognition_amd.engine import load_library
+    L = load_library()
+    out = (C.c_uint32 * 5)()
+
+    def geo(K, R):
+        assert L.sr_dtw_geometry(C.c_uint32(K), C.c_uint32(R), out) == 0
+        return tuple(out)
+
+    for R in (2, 16, 48, 119, 257, 320, 900, 2000, 5000):
+        for K in (1, 3, 10, 80, 100, 130, 500, 513, 700, 1024, 1500, 2050, 5000):
+            U, kc, g, lds, wgs = geo(K, R)
+            assert U >= 1 and 1 <= kc <= K and U * kc <= 1024, (K, R, U, kc)
+            assert g >= 4096 and g & (g - 1) == 0 and g <= 32768
+            gran = (lds + 1279) // 1280
+            assert wgs >= 1 and wgs * gran * 1280 <= 160 * 1024, (K, R, lds, wgs)
+    assert geo(100, 6000)[0] == 0                                   # no room for one utterance: generic kernel
+    assert geo(100, 320)[:3] == (5, 100, 8192) and geo(100, 320)[4] == 3       # BASELINE configs[2]: three workgroups per CU
+    U, kc, g, lds, wgs = geo(500, 320)                                          # configs[4]: several lanes per template row
+    assert U >= 6 and kc <= 170 and g >= 16384 and wgs == 2
