@@ -831,14 +831,9 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
         const int off = 2 * (it.s0 - 2 + kHopE * (int)(fi < it.nf ? fi : it.nf - 1) + 2 * base);  // groups past the last frame redo it
 #pragma unroll
         for (int t = 0; t < 10; t++) {
-#ifdef SR_EXT_NOLOAD  // timing experiment only: no sample traffic
-            qa[t] = 0x08000800u + (uint32_t)off;
-            qb[t] = 0x08010801u + (uint32_t)off;
-#else
             const u32x2 q2 = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 64 * t, 0, 0);
             qa[t] = q2.x;  // x[i-2] | x[i-1] << 16
             qb[t] = q2.y;  // x[i]   | x[i+1] << 16
-#endif
         }
         q_item = it_id;
         q_fb = fb;
