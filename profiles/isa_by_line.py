@@ -1,7 +1,7 @@
 """VALU instructions of one kernel attributed to source lines (development aid).
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -gline-tables-only -S --cuda-device-only -Iinclude \
-        -o /tmp/kg.s stm32_speech_recognition_amd/csrc/sr_kernels.hip
+        -o /tmp/kg.s stm32_speech_recognition_amd/csrc/k_mfcc.hip
   python profiles/isa_by_line.py /tmp/kg.s k_mfcc [.LBB0_44 ...]     (restrict to basic blocks)
 """
 import collections
@@ -31,7 +31,7 @@ def main():
         if m and (not only or blk in only):
             cnt[cur] += 1
             ops[cur][m.group(1)] += 1
-    src = open("stm32_speech_recognition_amd/csrc/sr_kernels.hip").read().split("\n")
+    src = open("stm32_speech_recognition_amd/csrc/k_mfcc.hip").read().split("\n")
     for ln, c in sorted(cnt.items()):
         top = " ".join(f"{k}:{v}" for k, v in ops[ln].most_common(4))
         print(f"{ln:5d} {c:4d}  {src[ln - 1].strip()[:70]:70s} | {top}")

@@ -1,7 +1,7 @@
 """Static per-basic-block instruction counts of one kernel in hipcc -S output (development aid).
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only -Iinclude \
-        -o /tmp/k.s stm32_speech_recognition_amd/csrc/sr_kernels.hip
+        -o /tmp/k.s stm32_speech_recognition_amd/csrc/k_mfcc.hip
   python profiles/isa_count.py /tmp/k.s k_mfcc
 """
 import collections

@@ -1,0 +1,260 @@
+// k_mfcc.hip -- get_mfcc (MFCC.C:86-191) incl. fft (MFCC.C:27-62) and cr4_fft_1024_stm32 (.s:95-281): the reference front end, one wave per frame.
+// gfx950 (MI355X, CDNA4) only; wave = 64 lanes; no MFMA (the path has no dense contraction), integer VALU + LDS.
+// Every kernel reproduces the reference's integer arithmetic bit for bit; cited lines are relative to the reference tree.
+#include "sr_fft_dev.h"
+
+namespace sr {
+
+// ------------------------------------------------------------------------------------------------
+// k_mfcc
+// ------------------------------------------------------------------------------------------------
+constexpr int kMfccWaves = 4;       // waves per workgroup
+constexpr int kFramesPerWave = 16;   // consecutive frames one wave turns into MFCCs per work item
+constexpr int kFramesPerTile = kMfccWaves * kFramesPerWave;
+// per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
+// rows of the filterbank outputs and of the DCT tables are kMelPad = 25 words apart: in the DCT the lanes of a wave read
+// 6 different frames x 12 different coefficients rows at the same column, and a stride of 24 folds those onto 4 banks
+constexpr int kMelPad = kMel + 1;
+constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMelPad + 64;  // the windowed frame aliases the exchange area;
+                                                                        // the last 64 words hold the odd filters' lane offsets
+
+__global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_dctM[kCoef * kMelPad];
+    __shared__ int s_dctS[kCoef * kMelPad];  // 32-bit: read with the wide LDS loads, no byte extraction
+    __shared__ u32x4 s_tw3[8 * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *buf = smem + w * kWaveLdsWords;
+    uint16_t *xw = (uint16_t *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
+    uint32_t *powb = buf + kXchgWords, *moff = powb + kFramesPerWave * kMelPad;
+
+    // DCT term (MFCC.C:179): (s32)pow * dct / 100, truncated toward zero, with 0 <= pow <= 2218 (= (u32)(ln(2^32)*100))
+    // and |dct| <= 128.  floor(pow*|c|/100) == (pow * M_c) >> 18 with M_c = ceil(|c| * 2^18 / 100) for every such pair
+    // (the rounding excess pow*eps/2^18 stays below 1/100 because 100*pow < 2^18); the log stage stores pow << 14 so
+    // the quotient is one v_mul_hi_u32, and the sign of c is applied by the accumulating 24-bit multiply.
+    for (int i = threadIdx.x; i < kCoef * kMel; i += blockDim.x) {
+        const int c = a.t.dct[i], o = (i / kMel) * kMelPad + i % kMel;
+        s_dctM[o] = (uint32_t)(((c < 0 ? -c : c) * 262144 + 99) / 100);
+        s_dctS[o] = (c > 0) - (c < 0);
+    }
+    __syncthreads();
+
+    // ---- lane-invariant constants --------------------------------------------------------------
+    LaneTw tw;
+    load_lane_tw(a.t, lane, tw);
+    if (w == 0 && lane < 4) {
+        const uint32_t *f = &tw.s3[0][0][0];
+#pragma unroll
+        for (int c = 0; c < 8; c++) s_tw3[lane * 8 + c] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+    }
+    if (w == 1 % kMfccWaves) store_tw32(s_tw5, lane, tw.s5);
+    __syncthreads();
+    int hamm_r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
+    // triangle weights of bins 8*lane .. 8*lane+7 of both poly-lines: 16 registers for the whole kernel
+    uint32_t tri_e[8], tri_o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        tri_e[k] = a.t.tri_even32[8 * lane + k];
+        tri_o[k] = a.t.tri_odd32[8 * lane + k];
+    }
+    // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
+    int f_lo = 0, f_hi = 0;
+    if (lane < kMel) {
+        const int h = lane;
+        f_lo = (h == 0) ? 0 : (int)a.t.tri_cen[h - 1];
+        f_hi = (h == kMel - 1) ? kBins : (int)a.t.tri_cen[h + 1];
+    }
+
+    // the per-utterance record of the NEXT work item is fetched while the current one is processed
+    uint32_t item = blockIdx.x;
+    uint32_t nx_nfrm = 0;
+    int nx_mid = 0, nx_seg0 = 0;
+    if (item < a.n_items) {
+        const sr_vad_rec *rec = a.vad + item / a.tiles;
+        nx_nfrm = rec->frm_num;
+        nx_mid = (int)rec->atap.mid_val;
+        nx_seg0 = rec->seg[0];
+    }
+    for (; item < a.n_items; item += gridDim.x) {
+        const uint32_t b = item / a.tiles, tile = item - b * a.tiles;
+        const uint32_t nfrm = nx_nfrm;
+        const int mid = nx_mid, seg0 = nx_seg0;
+        if (item + gridDim.x < a.n_items) {
+            const sr_vad_rec *rec = a.vad + (item + gridDim.x) / a.tiles;
+            nx_nfrm = rec->frm_num;
+            nx_mid = (int)rec->atap.mid_val;
+            nx_seg0 = rec->seg[0];
+        }
+        const uint16_t *row = a.pcm + (uint64_t)b * a.pcm_stride;
+        int16_t *out = a.mfcc + (uint64_t)b * a.max_frames * kCoef;
+        const uint32_t f0 = tile * kFramesPerTile + w * kFramesPerWave;
+        uint32_t nf = 0;  // frames this wave really has
+        if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFramesPerWave) ? nfrm - f0 : (uint32_t)kFramesPerWave;
+
+        // samples of frame fi+1 are requested while frame fi is transformed
+        // one 2-byte-aligned dword per sample: x[i-1] in the low half, x[i] in the high half
+        uint32_t s_pp[3] = {0, 0, 0};
+        if (nf) {
+            const uint16_t *x = row + seg0 + (int)kHop * (int)f0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int i = lane + 64 * k;
+                if (i < kFrameLen) s_pp[k] = *(const u32_align2 *)(x + i - 1);
+            }
+        }
+        for (uint32_t fi = 0; fi < nf; fi++) {
+            // ---- pre-emphasis + Hamming (MFCC.C:115-124); x[-1] is the sample before the frame
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int i = lane + 64 * k;
+                if (i < kFrameLen) {
+                    const int cur = (int)(s_pp[k] >> 16) - mid, prv = (int)(s_pp[k] & 0xFFFFu) - mid;
+                    const int t = cur - preemph95(prv);
+                    // stored as the pass-1 output A >> 2 of the s16 sample (16-bit LDS store; the gather zero-extends)
+                    xw[i] = (uint16_t)((int)(short)(mul24(t, hamm_r[k]) / 1000) >> 2);
+                }
+            }
+            if (fi + 1 < nf) {
+                const uint16_t *x = row + seg0 + (int)kHop * (int)(f0 + fi + 1);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int i = lane + 64 * k;
+                    if (i < kFrameLen) s_pp[k] = *(const u32_align2 *)(x + i - 1);
+                }
+            }
+            wave_sync();
+            // ---- FFT passes 1-3 in registers, exchange, passes 4-5 in registers
+            uint32_t v[4][4], u[4][4];
+            fft_front_real160(xw, lane, tw, s_tw3, v);
+            fft_exchange(buf, lane, v, u);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; e4++)
+                bfly_pk<false>(u[0][e4], u[1][e4], u[2][e4], u[3][e4], tw.s4[0][0], tw.s4[0][1], tw.s4[1][0], tw.s4[1][1],
+                               tw.s4[2][0], tw.s4[2][1], tw.s4[3][0], tw.s4[3][1]);
+            // pass 5: only x[j] and x[j+q] (bins < 512) are consumed (MFCC.C:49)
+            wave_sync();
+            uint32_t k5[4][4][2];
+            load_tw32(s_tw5, lane, k5);
+#pragma unroll
+            for (int e3 = 0; e3 < 4; e3++) {
+                bfly_pk<true>(u[e3][0], u[e3][1], u[e3][2], u[e3][3], k5[e3][0][0], k5[e3][0][1], k5[e3][1][0],
+                              k5[e3][1][1], k5[e3][2][0], k5[e3][2][1], k5[e3][3][0], k5[e3][3][1]);
+                // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
+                {
+                    // re*re + im*im from the packed word; both bins' roots and the x10 in packed f32 operations (plain IEEE
+                    // multiplies and fused multiply-adds, see sqrt_rn_int)
+                    const f32x2 m = sqrt_rn_int2(f32x2{(float)sdot2z(u[e3][0], u[e3][0]), (float)sdot2z(u[e3][1], u[e3][1])}) *
+                                    f32x2{10.0f, 10.0f};
+                    const uint32_t m0 = cvt_u32(m.x), m1 = cvt_u32(m.y);  // < 2^19
+                    buf[lane + 64 * e3] = umul24(m0, m0);
+                    buf[lane + 64 * e3 + 256] = umul24(m1, m1);
+                }
+            }
+            wave_sync();
+            // ---- Mel filterbank as prefix sums over bins (each term /100 before summing, u32 wrap)
+            uint32_t pe[8], po[8], xe, xo;
+            {
+                const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
+                const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                uint32_t se = 0, so = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    se += e[k] * tri_e[k] / 100u;
+                    so += e[k] * tri_o[k] / 100u;
+                    pe[k] = se;
+                    po[k] = so;
+                }
+                xe = wave_scan_incl(se) - se;  // sum over the bins of the lanes below
+                xo = wave_scan_incl(so) - so;
+            }
+            wave_sync();
+            // in-lane prefixes and the per-lane offsets are stored separately: the 24 filter lanes add them on lookup
+            // (2 adds) instead of every lane adding its offset to 16 prefixes
+            *(uint4 *)(buf + 8 * lane) = make_uint4(pe[0], pe[1], pe[2], pe[3]);
+            *(uint4 *)(buf + 8 * lane + 4) = make_uint4(pe[4], pe[5], pe[6], pe[7]);
+            *(uint4 *)(buf + kBins + 8 * lane) = make_uint4(po[0], po[1], po[2], po[3]);
+            *(uint4 *)(buf + kBins + 8 * lane + 4) = make_uint4(po[4], po[5], po[6], po[7]);
+            buf[2 * kBins + lane] = xe;
+            moff[lane] = xo;
+            wave_sync();
+            if (lane < kMel) {
+                const uint32_t *P = buf + ((lane & 1) ? kBins : 0), *X = (lane & 1) ? moff : buf + 2 * kBins;
+                const int ih = f_hi - 1, il = f_lo - 1;
+                const uint32_t hi = P[ih] + X[ih >> 3], lo = f_lo ? P[il] + X[il >> 3] : 0u;
+                powb[fi * kMelPad + lane] = hi - lo;
+            }
+            wave_sync();
+        }
+
+        // ---- log (MFCC.C:165-170) and DCT (MFCC.C:173-183) for the wave's nf frames, all lanes busy
+        // (the pad word of each row goes through the log as well: harmless, never read)
+        for (uint32_t t = lane; t < nf * kMelPad; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
+        wave_sync();
+        // output t = fi*12 + h of the wave's tile goes to out[(f0 + fi)*12 + h] = out_w[t]: consecutive lanes store
+        // consecutive s16; fi = t / 12 by a 24-bit multiply (exact for t < 2^13), all index arithmetic in 32 bits
+        // (left to the compiler the 64-bit subscript became eight v_mad_u64_u32 per round)
+        {
+            int16_t *out_w = out + (size_t)f0 * kCoef;
+#pragma unroll
+            for (uint32_t t = lane; t < (uint32_t)(kFramesPerWave * kCoef); t += 64) {
+                if (t < nf * kCoef) {
+                    const uint32_t fi = umul24(t, 10923u) >> 17, h = t - umul24(fi, (uint32_t)kCoef);
+                    const uint32_t *pw = powb + umul24(fi, (uint32_t)kMelPad), *dm = s_dctM + umul24(h, (uint32_t)kMelPad);
+                    const int *ds = s_dctS + umul24(h, (uint32_t)kMelPad);
+                    int acc = 0;
+#pragma unroll
+                    for (int i = 0; i < kMel; i++) acc = mad24((int)__umulhi(pw[i], dm[i]), ds[i], acc);
+                    out_w[t] = (int16_t)acc;
+                }
+            }
+        }
+        wave_sync();
+        // rows >= frm_num of this tile are zeroed so that every row of the output is defined
+        {
+            const uint32_t r0 = f0 + nf, r1 = (f0 + kFramesPerWave < a.max_frames) ? f0 + kFramesPerWave : a.max_frames;
+            for (uint32_t t = r0 * kCoef + lane; t < r1 * kCoef && r0 < r1; t += 64) out[t] = 0;
+        }
+    }
+}
+
+// the 16 kHz / 512-point EXTENSION front end lives in k_mfcc_ext.hip
+uint32_t mfcc_ext_frames_per_tile();
+int mfcc_ext_occupancy(int *per_cu);
+void launch_mfcc_ext(const MfccArgs &a, uint32_t grid, hipStream_t s);
+
+uint32_t mfcc_frames_per_tile(uint32_t frame_len) { return frame_len == 320 ? mfcc_ext_frames_per_tile() : (uint32_t)kFramesPerTile; }
+
+// workgroups of the frame kernel that fit on the current device at once (occupancy query x CU count)
+uint32_t mfcc_resident_workgroups(uint32_t frame_len)
+{
+    int dev = 0, n_cu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return 0;
+    int e;
+    if (frame_len == 320)
+        e = mfcc_ext_occupancy(&per_cu);
+    else
+        e = (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc, 64 * kMfccWaves,
+                                                              (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t));
+    if (e != (int)hipSuccess || per_cu < 1) return 0;
+    return (uint32_t)(per_cu * n_cu);
+}
+
+void launch_mfcc(const MfccArgs &a, hipStream_t s)
+{
+    if (a.n_items == 0) return;
+    // persistent-style grid: a few times the workgroups that are resident at once (see sr_create), work items strided
+    const uint32_t cap = a.grid_cap ? a.grid_cap : 4096u;
+    const uint32_t grid = a.n_items < cap ? a.n_items : cap;
+    if (a.frame_len == 320) {
+        launch_mfcc_ext(a, grid, s);
+        return;
+    }
+    const size_t lds = (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_mfcc, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
+}
+
+}  // namespace sr

@@ -1,0 +1,96 @@
+// k_misc.hip -- delta cepstra (EXTENSION), and the scalar diagnostics / compat helpers: log / sqrt device functions swept directly, get_dis, dtw_limit.
+// gfx950 (MI355X, CDNA4) only; wave = 64 lanes; no MFMA (the path has no dense contraction), integer VALU + LDS.
+// Every kernel reproduces the reference's integer arithmetic bit for bit; cited lines are relative to the reference tree.
+#include "sr_dtw_dev.h"
+
+namespace sr {
+
+// ------------------------------------------------------------------------------------------------
+// k_delta_mfcc: EXTENSION, no reference counterpart (the accompanying thesis, p.32, lists difference cepstra as future
+// work).  Two-frame regression over the s16 MFCC rows of a record, d[t] = ((m[t+1]-m[t-1]) + 2(m[t+2]-m[t-2])) / 10 with
+// rows clamped to [0, n-1], s32 arithmetic, division truncating toward zero (as every division of MFCC.C); rows >= n
+// are zero.  Defined in oracle/sr_oracle.c (sr_oracle_delta_mfcc); pure streaming: one thread per output element.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames,
+                                                    uint32_t B, uint32_t max_frames, int16_t *delta)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per = max_frames * kCoef;
+    if (i >= (uint64_t)B * per) return;
+    const uint32_t b = (uint32_t)(i / per), r = (uint32_t)(i - (uint64_t)b * per), t = r / kCoef, c = r - t * kCoef;
+    uint32_t n = frames ? frames[b] : ((vad[b].status == SR_ST_OK) ? vad[b].frm_num : 0u);
+    if (n > max_frames) n = max_frames;
+    int16_t out = 0;
+    if (t < n) {
+        const int16_t *m = mfcc + (uint64_t)b * per + c;
+        const uint32_t p1 = t + 1 < n ? t + 1 : n - 1, p2 = t + 2 < n ? t + 2 : n - 1;
+        const uint32_t m1 = t >= 1 ? t - 1 : 0, m2 = t >= 2 ? t - 2 : 0;
+        const int num = ((int)m[p1 * kCoef] - (int)m[m1 * kCoef]) + 2 * ((int)m[p2 * kCoef] - (int)m[m2 * kCoef]);
+        out = (int16_t)(num / 10);
+    }
+    delta[i] = out;
+}
+void launch_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames, uint32_t B, uint32_t max_frames,
+                       int16_t *delta, hipStream_t s)
+{
+    const uint64_t n = (uint64_t)B * max_frames * kCoef;
+    if (!n) return;
+    hipLaunchKernelGGL(k_delta_mfcc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, mfcc, vad, frames, B, max_frames, delta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// diagnostics: the three non-integer device functions on their own, so tests can sweep them directly
+//   out[3i+0] = (u32)(log((double)x)*100)                       MFCC.C:168   (step-function evaluation)
+//   out[3i+1] = (u32)sqrtf((float)x)                            DTW.C:59     (v_rsq_f32 seed + fused correction, sqrt_rn_int)
+//   out[3i+2] = (u32)(sqrtf((float)(s32)x)*10), x < 2^31        MFCC.C:56-58
+// ------------------------------------------------------------------------------------------------
+__global__ void k_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *log_thr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = in[i];
+    out[3 * i + 0] = log100_u32(x, log_thr);
+    // the exact routine and the bracketed fast path of the DTW kernel are reported through one word: the exact value,
+    // or a poison value if the fast path claims "safe" and disagrees (tests/exhaustive_math_sweep.py: all 2^32 inputs)
+    {
+        bool unsafe = false;
+        const uint32_t q = sqrt_floor_bracket(x, unsafe), e = cvt_u32(sqrt_rn_int((float)x));
+        out[3 * i + 1] = (unsafe || q == e) ? e : 0xDEAD0001u;
+    }
+    out[3 * i + 2] = cvt_u32(sqrt_rn_int((float)(int)(x & 0x7FFFFFFFu)) * 10.0f);
+}
+void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_math_diag, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, t.log_thr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers of DTW.C exposed by the reference-compatible symbols
+// ------------------------------------------------------------------------------------------------
+__global__ void k_get_dis(const int16_t *pa, const int16_t *pb, uint32_t *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Frame12 fa = load_frame(pa + (size_t)i * kCoef), fb = load_frame(pb + (size_t)i * kCoef);
+    out[i] = get_dis_dev(fa, norm2(fa), fb, norm2(fb));
+}
+void launch_get_dis(const int16_t *pa, const int16_t *pb, uint32_t *out, uint32_t n, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_get_dis, dim3((n + 63) / 64), dim3(64), 0, s, pa, pb, out, n);
+}
+
+__global__ void k_dtw_limit(const uint16_t *xy, uint8_t *out, uint32_t n, int X1, int X2, int in_n, int mdl_n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = dtw_out((int)xy[2 * i], (int)xy[2 * i + 1], X1, X2, in_n, mdl_n) ? 1 : 0;
+}
+void launch_dtw_limit(const uint16_t *xy, uint8_t *out, uint32_t n, int X1, int X2, int in_n, int mdl_n, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_dtw_limit, dim3((n + 63) / 64), dim3(64), 0, s, xy, out, n, X1, X2, in_n, mdl_n);
+}
+
+}  // namespace sr

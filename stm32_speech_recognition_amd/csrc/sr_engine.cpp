@@ -602,6 +602,8 @@ static int check_pcm(const sr_engine *h, const uint16_t *pcm, uint64_t stride, u
     if (buf_len > stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
     if (buf_len < h->noise_len || buf_len <= h->frame_len) return fail(SR_ERR_BAD_ARG, "buf_len shorter than the noise head");
     if (buf_len > 0x7FFFFFF0u) return fail(SR_ERR_BAD_ARG, "buf_len too large");
+    // the extension frame kernel addresses a capture row through a raw buffer resource of 2 * pcm_stride bytes (32 bits)
+    if (stride >= (1ull << 31)) return fail(SR_ERR_BAD_ARG, "pcm_stride must be below 2^31 samples");
     return SR_OK;
 }
 
@@ -640,6 +642,7 @@ int sr_mfcc_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, 
                       int16_t *d_mfcc, void *stream)
 {
     if (!h || !d_pcm || !d_vad || !d_mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (pcm_stride >= (1ull << 31)) return fail(SR_ERR_BAD_ARG, "pcm_stride must be below 2^31 samples");
     if (int rcb = check_batch(h, B)) return rcb;
     ENTER_DEVICE(h);
     launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, d_vad, d_mfcc), (hipStream_t)stream);
@@ -949,8 +952,12 @@ int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
     return SR_OK;
 }
 
-int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
-                  const int32_t *start, const int32_t *end, const uint32_t *mid, int16_t *mfcc, uint32_t *frm_num)
+// Per-item failure, as get_mfcc has it (MFCC.C:102-107: a segment shorter than a frame underflows the u32 frame count,
+// which then exceeds vv_frm_max -> frm_num = 0): one bad record yields frm_num[b] = 0, an all-zero MFCC record and
+// status[b] != 0; the other records of the batch are processed.
+int sr_mfcc_batch_status(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                         const int32_t *start, const int32_t *end, const uint32_t *mid, int16_t *mfcc, uint32_t *frm_num,
+                         uint32_t *status)
 {
     if (!h || !pcm || !start || !end || !mid || !mfcc) return fail(SR_ERR_BAD_ARG, "null argument");
     if (B == 0) return SR_OK;
@@ -968,12 +975,18 @@ int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32
         for (int i = 0; i < 2 * SR_MAX_SEG; i++) r.seg[i] = -1;
         r.seg[0] = start[b];
         r.seg[1] = end[b];
-        if (start[b] < 1 || end[b] > (int32_t)buf_len || end[b] - start[b] < (int32_t)h->frame_len)
-            return fail(SR_ERR_BAD_ARG, "segment outside the buffer (start must be >= 1: MFCC.C:119 reads start[-1])");
-        const uint32_t n = ((((uint32_t)(end[b] - start[b]) - h->frame_len) / h->hop) + 1) & 0xFFFF;  // MFCC.C:102
-        r.status = n > h->cfg.max_frames ? SR_ST_MFCC_FAIL : SR_ST_OK;                           // MFCC.C:103-107
-        r.frm_num = n > h->cfg.max_frames ? 0 : n;
+        if (start[b] < 1 || end[b] > (int32_t)buf_len || end[b] < start[b]) {
+            r.status = SR_ST_SEG_OOB;  // outside the buffer (start >= 1: MFCC.C:119 reads start[-1])
+        } else {
+            // MFCC.C:102: u32 arithmetic, u16 truncation -- a segment shorter than a frame wraps to a count above the cap
+            const uint32_t n = ((((uint32_t)(end[b] - start[b]) - h->frame_len) / h->hop) + 1) & 0xFFFF;
+            const bool shorter = (uint32_t)(end[b] - start[b]) < h->frame_len;  // the wrapped count may alias a small one
+            r.status = (shorter || n > h->cfg.max_frames) ? SR_ST_MFCC_FAIL : SR_ST_OK;  // MFCC.C:103-107
+            r.frm_num = r.status == SR_ST_OK ? n : 0;
+        }
+        if (r.status != SR_ST_OK) r.seg[0] = 1, r.seg[1] = 1;  // never dereferenced (no frames); keep the record harmless
         if (frm_num) frm_num[b] = r.frm_num;
+        if (status) status[b] = r.status;
     }
     uint64_t ds = 0;
     int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
@@ -984,6 +997,12 @@ int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32
     if ((rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, B, h->s_vad.p, h->s_mfcc.p, nullptr))) return rc;
     HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * kCoef * 2, hipMemcpyDeviceToHost));
     return SR_OK;
+}
+
+int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                  const int32_t *start, const int32_t *end, const uint32_t *mid, int16_t *mfcc, uint32_t *frm_num)
+{
+    return sr_mfcc_batch_status(h, pcm, pcm_stride, buf_len, B, start, end, mid, mfcc, frm_num, nullptr);
 }
 
 // Template training: save_mdl (main.c:121-138) for n captures + the slot image save_ftr_mdl programs
