@@ -74,6 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the extra N = 1 measurements of configs[1] and configs[4] (other_configs)")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each other_configs entry")
+    ap.add_argument("--scorer", choices=["greedy", "dp"], default="greedy",
+                    help="greedy = the reference's dtw() (the metric); dp = time ONLY the opt-in NON-REFERENCE full-DP scorer "
+                         "(sr_dtw_dp_batch_dev) on the same features -- a side measurement, never the headline metric")
+    ap.add_argument("--dp-lanes", type=int, default=0, help="--scorer dp: lanes per pair (0 default = 8; 4, 8, 16; 1 = first version)")
     ap.add_argument("--other-scale", type=int, default=1,
                     help="tests: divide the other_configs batches by this and run them whatever the headline shape is")
     return ap.parse_args(argv)
@@ -288,6 +292,193 @@ def other_config(workload, B, Kt, steps, local_rank, cpu_n):
     return e
 
 
+def dp_cells_per_pair(in_n, tfr):
+    """cells of the dtw_limit parallelogram (DTW.C:76-109) summed over the templates that pass the length gate, for
+    utterances of in_n frames: the work of the full-DP scorer, counted with the same interval form the kernel uses"""
+    tot, pairs = 0, 0
+    for m in (int(v) for v in tfr):
+        if in_n > 2 * m or 2 * in_n < m:
+            continue
+        X1, X2 = int((2 * m - in_n) / 3), int((4 * in_n - 2 * m) / 3)
+        x = np.arange(1, in_n + 1)
+        ub = np.where(x < X1, 2 * x + 1, ((x + 5 - in_n + 2 * m) >> 1) - 1)
+        lb = np.where(x < X2, x >> 1, 2 * x + m - 2 * in_n - 3)
+        tot += int(np.maximum(0, np.minimum(ub, m) - np.maximum(lb, 1) + 1).sum())
+        pairs += 1
+    return tot / max(pairs, 1), pairs
+
+
+def measure_dp(B, Kt, steps, lanes, local_rank, parity_n=64):
+    """the opt-in NON-REFERENCE full-DP scorer alone: features of B synthetic 256-frame utterances (computed once, resident
+    in HBM) against Kt templates, `steps` timed launches of sr_dtw_dp_batch_dev; parity of a sample against its own oracle"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    dev = torch.device("cuda", local_rank)
+    eng = Engine(max_frames=MAX_FRAMES, device=local_rank)
+    bank = synth.word_bank(N_WORDS_DEFAULT)
+    tm, tfr, rng = make_templates(eng, bank, Kt, N_WORDS_DEFAULT, 1, dev)
+    eng.set_templates_dense(tm, tfr.astype(np.uint32))
+    eng.set_dp_lanes(lanes)
+    vads, mfs = [], []
+    for b0 in range(0, B, 16384):  # features chunk by chunk: the capture buffers are not needed afterwards
+        n = min(16384, B - b0)
+        pcm = synth.make_utterances(torch.from_numpy(rng.integers(0, N_WORDS_DEFAULT, n)), [T] * n, seed=3000 + b0, bank=bank,
+                                    S=synth.buf_len_for(T), device=dev)
+        v, m = eng.features_dev(pcm)
+        torch.cuda.synchronize()
+        vads.append(v)
+        mfs.append(m)
+        del pcm
+    vad, mfcc = torch.cat(vads), torch.cat(mfs)
+    del vads, mfs
+    sc = torch.empty(B, Kt, dtype=torch.int32, device=dev)
+    eng.dtw_dp_dev(mfcc, sc, vad=vad)  # warm-up
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        eng.dtw_dp_dev(mfcc, sc, vad=vad)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    cells, pairs_ok = dp_cells_per_pair(T, tfr)
+    n = min(parity_n, B)
+    parity = None
+    if n:
+        orc = ol.Oracle(max_frames=MAX_FRAMES)
+        cores = usable_cores()[0]
+        t1 = time.perf_counter()
+        want = orc.dtw_dp_batch(mfcc[:n].cpu().numpy(), np.full(n, T, np.uint32), tm, tfr.astype(np.uint32), n_threads=cores)
+        cpu_s = time.perf_counter() - t1
+        same = bool(np.array_equal(sc[:n].cpu().numpy().view(np.uint32), want))
+        parity = {"identical": same, "pairs": n * Kt, "checker": "sr_oracle_dtw_dp (own definition; no reference counterpart)",
+                  "cpu_pairs_per_s": n * Kt / cpu_s, "cpu_cores": cores}
+    name = {0: "k_dtw_dp_band<8>", 4: "k_dtw_dp_band<4>", 8: "k_dtw_dp_band<8>", 16: "k_dtw_dp_band<16>", 1: "k_dtw_dp_wave64"}[lanes]
+    e = {"workload": f"OPT-IN NON-REFERENCE full-DP scorer alone: {B} utterances (256 frames) x {Kt} templates (192..320 frames), "
+                     "features resident in HBM", "kernel": name, "lanes_per_pair": lanes or 8,
+         "value": B * steps / dt, "unit": "utterances/s", "pairs_per_s": B * Kt * steps / dt, "ms_per_step": dt / steps * 1e3,
+         "kernel_ms": float(np.mean(kms)), "steps": steps, "warmup": 1,
+         "cells_per_pair": cells, "cells_per_s": B * pairs_ok * cells * steps / dt,
+         "parity_on_sample": parity,
+         "note": "the reference's dtw() is a greedy walk (DTW.C:150-188); this scorer never backs dtw() or the recognition path"}
+    vpath = os.path.join(ROOT, "profiles", "pmc_valu_dp.json")
+    if os.path.exists(vpath) and lanes in (0, 8):
+        try:
+            vj = json.load(open(vpath))
+            if pmc_is_current(vj, "pmc_valu_dp.json"):
+                slots = vj["k_dtw_dp_valu_slots_per_pair"]
+                ach = slots * B * Kt / (float(np.mean(kms)) * 1e-3)
+                e["roofline_valu"] = {"bound": "valu-issue", "achieved": ach, "peak": 1024 * 2.4e9 / 4.0, "frac": ach / (1024 * 2.4e9 / 4.0),
+                                      "unit": "4-cycle issue slots/s", "valu_slots_per_pair": slots, "source": vj.get("source")}
+        except Exception:
+            pass
+    eng.close()
+    return e
+
+
+def latency_block(local_rank, n_utt=64):
+    """Side figure (never part of `value`): what ONE call of the drop-in symbols costs, next to the reference's own objects
+    on one host core.  The firmware's shapes: 16 000-sample capture (ADC.H:8-9), 119-frame cap, an 80-slot store
+    (comm_num * ftr_per_comm, Flash.H:15-17) trained through the same front end (main.c:121-138).
+      spch_recg      one capture -> label + distance (main.c:249-296): upload, VAD, MFCC, DTW x 80, argmin, read-back
+      get_mfcc       one segment -> v_ftr_tag (MFCC.C:86-191)
+      dtw slot scan  main.c:279-291's loop: 80 dtw() calls for one input record (the symbol scores the record against every
+                     cached model in ONE launch, the other 79 calls are look-ups)
+      sr_recognize_batch_dev at B = 1, 16, 256 on device-resident captures, synchronised after every call"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from stm32_speech_recognition_amd import compat
+    Tl, S, Kl = 110, 16000, 80
+    dev = torch.device("cuda", local_rank)
+    eng = Engine(max_frames=119, device=local_rank)
+    bank = synth.word_bank(N_WORDS_DEFAULT)
+    rng = np.random.default_rng(4)
+    tfr = rng.integers(70, 120, Kl)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(Kl) % N_WORDS_DEFAULT, tfr, seed=8, bank=bank, S=S))
+    store, st = eng.train_store(tp, np.arange(Kl), n_slots=Kl)
+    assert (st == 0).all()
+    eng.set_templates_store(store)
+    compat.set_templates(store)
+    words = rng.integers(0, N_WORDS_DEFAULT, n_utt)
+    pcm = synth.as_u16_numpy(synth.make_utterances(words, [Tl] * n_utt, seed=9, bank=bank, S=S))
+    ref = ol.RefLib() if ol.RefLib.available() else None
+
+    def us(fn, n):
+        fn(0)  # warm-up (first call creates the implicit engine / uploads the store)
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        return (time.perf_counter() - t0) / n * 1e6
+
+    out = {"shape": f"{S}-sample captures, {Tl}-frame words, {Kl}-slot store, 119-frame cap (the firmware's constants)",
+           "unit": "microseconds per call, host wall clock, one call in flight (python ctypes loop: ~2 us of interpreter per call)"}
+    # ---- spch_recg
+    g = [None] * n_utt
+    r = [None] * n_utt
+
+    def f_spch(i):
+        g[i] = compat.spch_recg(pcm[i])
+    out["spch_recg_us"] = us(f_spch, n_utt)
+    if ref is not None:
+        def f_rspch(i):
+            r[i] = ref.spch_recg(pcm[i], store)
+        out["spch_recg_reference_objects_us"] = us(f_rspch, n_utt)
+        out["spch_recg_identical"] = bool(all(r[i][0] == 0 and g[i][1] == r[i][2] for i in range(n_utt)))
+    # ---- get_mfcc on the VAD's first segment
+    atap = compat.atap_tag()
+    compat.noise_atap(pcm[0], 2400, atap)
+    segs = compat.VAD(pcm[0], S, atap)
+    s0, e0 = segs[0]
+    ftrs = [None]
+
+    def f_mfcc(i):
+        ftrs[0] = compat.get_mfcc(pcm[0], s0, e0, atap)
+    out["get_mfcc_us"] = us(f_mfcc, 32)
+    if ref is not None:
+        ra, rseg = ref.vad(pcm[0])
+        out["get_mfcc_reference_objects_us"] = us(lambda i: ref.mfcc(pcm[0], int(rseg[0]), int(rseg[1]), ra), 32)
+    # ---- dtw(): the slot scan of main.c:279-291
+    slots = [compat.v_ftr_tag.from_buffer_copy(bytes(store[k * 4096:k * 4096 + 2860])) for k in range(Kl)]
+    ins = []
+    for i in range(8):
+        compat.noise_atap(pcm[i], 2400, atap)
+        sg = compat.VAD(pcm[i], S, atap)
+        ins.append(compat.get_mfcc(pcm[i], sg[0][0], sg[0][1], atap))
+    sc = np.zeros((8, Kl), np.uint32)
+
+    def f_scan(i):
+        for k in range(Kl):
+            sc[i % 8, k] = compat.dtw(ins[i % 8], slots[k])
+    out["dtw_slot_scan_us"] = us(f_scan, 16)
+    out["dtw_per_call_us"] = out["dtw_slot_scan_us"] / Kl
+    if ref is not None:
+        rslots = [np.frombuffer(bytes(store[k * 4096:k * 4096 + 2860]), np.uint8).copy() for k in range(Kl)]
+        rins = [np.frombuffer(bytes(f), np.uint8).copy() for f in ins]
+        rsc = np.zeros((8, Kl), np.uint32)
+
+        def f_rscan(i):
+            for k in range(Kl):
+                rsc[i % 8, k] = ref.dtw(rins[i % 8], rslots[k])
+        out["dtw_slot_scan_reference_objects_us"] = us(f_rscan, 16)
+        out["dtw_identical"] = bool(np.array_equal(sc, rsc))
+    # ---- batched device-resident entry point at small B
+    dpcm = torch.from_numpy(pcm.view(np.int16)).to(dev)
+    dpcm = dpcm.repeat((256 + n_utt - 1) // n_utt, 1)[:256].contiguous()
+    for Bs in (1, 16, 256):
+        o = eng.alloc_outputs(Bs, dev, mfcc=False, vad=False)
+
+        def f_dev(i):
+            eng.recognize_dev(dpcm[:Bs], o)
+            torch.cuda.synchronize()
+        t = us(f_dev, 50)
+        out[f"sr_recognize_batch_dev_B{Bs}_us"] = t
+        out[f"sr_recognize_batch_dev_B{Bs}_us_per_utterance"] = t / Bs
+    eng.close()
+    return out
+
+
 def claim_stdout():
     """The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when a communicator is created
     (five lines: "RCCL version : ...", "HIP version", "ROCm version", "Hostname", "Librccl path"), and other libraries may do
@@ -334,6 +525,17 @@ def run_rank(args):
         du.init_process_group(backend, local_rank)
     torch.cuda.set_device(local_rank)
     B = args.batch
+    if args.scorer == "dp":
+        if world != 1 or args.workload != "ref":
+            raise SystemExit("--scorer dp is a single-GPU side measurement of the reference workload")
+        e = measure_dp(B, args.templates or K_DEFAULT, args.steps, args.dp_lanes, local_rank)
+        line = {"metric": f"utterances/sec (256-frame, {args.templates or K_DEFAULT} templates; OPT-IN full-DP scorer alone, NON-REFERENCE, "
+                          "not the headline metric)", "value": e["value"], "unit": "utterances/s", "n_gpus": 1, "steps": args.steps,
+                "warmup": 1, "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "int32", "data": "synthetic", "config": {"workload": e["workload"]}, "dp": e}
+        out_stream.write(json.dumps(line) + "\n")
+        out_stream.flush()
+        return 0
     m = measure(args.workload, B, args.templates, args.steps, args.warmup, rank, world, local_rank, dist)
     if rank == 0:
         line = headline(args, m, world, backend)
@@ -343,6 +545,7 @@ def run_rank(args):
             line["cpu_baseline"] = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], args.cpu_sample, m["eng_cfg"])
             if args.workload == "ref":
                 line["cpu_reference_objects"] = cpu_reference_objects(local_rank)
+                line["latency"] = latency_block(local_rank)
         default_shape = args.workload == "ref" and (B, m["K"]) == (65536, 100)
         if world == 1 and (default_shape or args.other_scale > 1) and not args.no_other_configs:
             # the other single-GPU shapes BASELINE.json names, under the same clock (never part of `value`)
@@ -353,12 +556,38 @@ def run_rank(args):
             sc = args.other_scale
             line["other_configs"] = [other_config("ref", 4096 // sc, 10, args.other_steps, local_rank, cpu_n),
                                      other_config("ext", 65536 // sc, 500, args.other_steps, local_rank, cpu_n and 128)]
+            # the scorer BASELINE.json's north_star describes (anti-diagonal wavefront), opt-in and non-reference: timed alone
+            line["other_configs"].append(measure_dp(65536 // sc, K_DEFAULT, min(3, args.other_steps), 0, local_rank,
+                                                    parity_n=64 if cpu_n else 0))
         out_stream.write(json.dumps(line) + "\n")
         out_stream.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+PMC_SOURCES = {  # the translation units (+ the device headers they include) each committed PMC file depends on
+    "pmc_traffic.json": ("k_mfcc.hip", "sr_dev.h", "sr_fft_dev.h", "sr_device.h"),
+    "pmc_valu.json": ("k_vad.hip", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
+    "pmc_valu_dp.json": ("k_dtw_dp.hip", "sr_dev.h", "sr_dtw_dev.h", "sr_device.h"),
+}
+
+
+def kernel_sources_sha(which):
+    """sha256 over the kernel sources a committed PMC file (profiles/pmc_*.json) was measured with; profiles/summarize.py
+    stores it in the file, and a figure whose kernels have changed since is reported as stale instead of being used"""
+    import hashlib
+    d = os.path.join(ROOT, "stm32_speech_recognition_amd", "csrc")
+    h = hashlib.sha256()
+    for f in PMC_SOURCES[which]:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_is_current(j, which):
+    return j.get("kernel_sources_sha") == kernel_sources_sha(which)
 
 
 def headline(args, m, world, backend="nccl", launcher=None):
@@ -377,12 +606,15 @@ def headline(args, m, world, backend="nccl", launcher=None):
     # the same kernel alone on the chip: ONE launch over all B utterances (the extra pass right after the timed steps)
     ach_iso = by_mfcc * B / (stage_iso["mfcc"] * 1e-3) / 1e9
     traffic = traffic_iso = traffic_src = None
+    traffic_stale = valu_stale = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if args.workload == "ref" and os.path.exists(tpath):
         try:  # the PMC passes measured one whole-batch launch over tj["B"] utterances; traffic scales with utterances
             tj = json.load(open(tpath))
-            traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]
-            traffic_iso = tj["k_mfcc_hbm_bytes_per_launch"] * B / tj["B"]
+            traffic_stale = not pmc_is_current(tj, "pmc_traffic.json")
+            if not traffic_stale:
+                traffic = tj["k_mfcc_hbm_bytes_per_launch"] * (B / launches) / tj["B"]
+                traffic_iso = tj["k_mfcc_hbm_bytes_per_launch"] * B / tj["B"]
             traffic_src = tj.get("source")
         except Exception:
             traffic = traffic_iso = None
@@ -396,6 +628,9 @@ def headline(args, m, world, backend="nccl", launcher=None):
     if args.workload == "ref" and Kt == 100 and os.path.exists(vpath):
         try:
             vj = json.load(open(vpath))
+            valu_stale = not pmc_is_current(vj, "pmc_valu.json")
+            if valu_stale:
+                raise ValueError("stale")
             insts = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
             slots = sum(v for k, v in vj.items() if k.endswith("_valu_slots_per_utt")) or insts
             peak = 1024 * 2.4e9 / 4.0
@@ -432,8 +667,10 @@ def headline(args, m, world, backend="nccl", launcher=None):
         # its stream, in the pass right after the timed steps) -- the figure profiles/*_rocprof_summary.csv reproduces.
         "roofline": {"bound": "hbm", "kernel": "k_mfcc" if rate == 1 else "k_mfcc_ext", "achieved": ach_iso,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_iso / HBM_PEAK_GBS, "traffic": traffic_iso,
-                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by_mfcc * B,
+                     "traffic_source": traffic_src, "traffic_stale": traffic_stale, "algorithmic_bytes_per_launch": by_mfcc * B,
                      "kernel_ms": stage_iso["mfcc"], "launches_per_step": 1, "utterances_per_launch": B,
+                     "pass": "isolated (untimed pass right after the timed steps); `value` / `ms_per_step` come from the pipelined "
+                             "timed steps, whose per-launch figures are under `overlapped`",
                      "measured": "hipEvents around the launch on its own stream; whole batch as ONE launch, kernel alone on "
                                  "the chip (extra pass right after the timed steps; agrees with the rocprof 'whole batch' row)",
                      "overlapped": {"achieved": ach_ovl, "frac": ach_ovl / HBM_PEAK_GBS, "kernel_ms": stage["mfcc"],
@@ -447,6 +684,7 @@ def headline(args, m, world, backend="nccl", launcher=None):
                           "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "note": "whole step (all chunks, fork -> join on the launch stream)"},
         "roofline_valu": roofline_valu,
+        "roofline_valu_stale": valu_stale,  # true: profiles/pmc_valu.json was measured with other kernel sources -> figure dropped
         "kernel_ms": stage,
         "kernel_ms_isolated": {**stage_iso, "note": "untimed extra pass: whole batch as one chunk on one stream (no overlap)"},
         "top1_word_accuracy": m["acc"],

@@ -176,6 +176,15 @@ int sr_vad_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_
 /* MFCC of segment [start[b], end[b]) of buffer b with mid value mid[b]; frm_num[b] receives the frame count */
 int sr_mfcc_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                   const int32_t *start, const int32_t *end, const uint32_t *mid, int16_t *mfcc, uint32_t *frm_num);
+/* The same with PER-RECORD failure, as get_mfcc has it (MFCC.C:102-107: a segment shorter than a frame underflows the u32
+ * frame count, which then exceeds vv_frm_max -> frm_num = 0): a bad record yields frm_num[b] = 0, an all-zero MFCC record
+ * and status[b] = SR_ST_SEG_OOB (start < 1, end beyond the buffer, end < start) or SR_ST_MFCC_FAIL (shorter than a frame,
+ * more than max_frames frames); the other records of the batch are processed.  sr_mfcc_batch is this call with
+ * status == NULL.  (One deviation from the literal u16 arithmetic of MFCC.C:102: a segment shorter than a frame always
+ * fails; the wrapped count 13107 would pass a cap of 13107 frames or more and read far beyond the segment.) */
+int sr_mfcc_batch_status(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                         const int32_t *start, const int32_t *end, const uint32_t *mid, int16_t *mfcc, uint32_t *frm_num,
+                         uint32_t *status);
 /* all-pairs greedy DTW of B feature sequences (in_mfcc[b*max_frames*n_coef], in_frames[b]) against the store */
 int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores,
                  sr_result *results);
@@ -196,6 +205,11 @@ int sr_get_mdl_batch(sr_engine *h, const int16_t *in1, const uint32_t *n1, uint3
  *   D(1,1)=d(1,1); D(x,y)=d(x,y)+min(D(x-1,y-1),D(x-1,y),D(x,y-1)); score = D(in,mdl)/(in+mdl), dis_err if gated/unreachable.
  * The reference's dtw() is a greedy walk (DTW.C:150-188), so these scores differ from dtw()'s by design and are
  * never used by sr_recognize_* or the dtw symbol. */
+/* Kernel: a band-limited anti-diagonal wavefront, `lanes` lanes of a wave per (utterance, template) pair (strips of that
+ * many utterance frames; the value from the left moves by DPP, strip boundaries through LDS, the template staged in LDS);
+ * sr_set_dp_lanes chooses 4, 8 (default, 0) or 16, or 1 = the first version (one wave per pair, 64-column sweeps of the
+ * whole rectangle), which also serves stores the band kernel cannot stage.  All variants give identical scores. */
+int sr_set_dp_lanes(sr_engine *h, uint32_t lanes);
 int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores);
 int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_in_frames, const sr_vad_rec *d_vad,
                         uint32_t B, uint32_t *d_scores, void *stream);

@@ -563,6 +563,41 @@ uint32_t sr_oracle_dtw_dp(const int16_t *in, uint32_t in_n, const int16_t *mdl, 
     return res;
 }
 
+/* all pairs of B records x K templates through sr_oracle_dtw_dp, split over n_threads host threads (test helper):
+ * in [B][in_rows][nc], in_n[B]; mdl [K][mdl_rows][nc], mdl_n[K] (0 = invalid slot -> dis_err); out [B][K] */
+typedef struct {
+    const int16_t *in, *mdl;
+    const uint32_t *in_n, *mdl_n;
+    uint32_t in_rows, mdl_rows, K, nc, b0, b1;
+    uint32_t *out;
+} dp_job;
+static void *dp_worker(void *arg)
+{
+    dp_job *j = arg;
+    for (uint32_t b = j->b0; b < j->b1; b++)
+        for (uint32_t k = 0; k < j->K; k++)
+            j->out[(size_t)b * j->K + k] = sr_oracle_dtw_dp(j->in + (size_t)b * j->in_rows * j->nc, j->in_n[b],
+                                                            j->mdl + (size_t)k * j->mdl_rows * j->nc, j->mdl_n[k], j->nc);
+    return NULL;
+}
+void sr_oracle_dtw_dp_batch(const int16_t *in, const uint32_t *in_n, uint32_t in_rows, uint32_t B, const int16_t *mdl,
+                            const uint32_t *mdl_n, uint32_t mdl_rows, uint32_t K, uint32_t nc, uint32_t *out,
+                            uint32_t n_threads)
+{
+    pthread_t th[256];
+    dp_job jobs[256];
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    if (n_threads > B) n_threads = B ? B : 1;
+    for (uint32_t t = 0; t < n_threads; t++) {
+        dp_job j = {in, mdl, in_n, mdl_n, in_rows, mdl_rows, K, nc, (uint32_t)((uint64_t)B * t / n_threads),
+                    (uint32_t)((uint64_t)B * (t + 1) / n_threads), out};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, dp_worker, &jobs[t]);
+    }
+    for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+}
+
 /* ---- main.c:249-296 ----------------------------------------------------- */
 static void recognize_segment(const sr_oracle *o, const uint16_t *pcm, uint32_t buf_len, const sr_oracle_templates *tpl,
                               uint32_t seg_idx, sr_oracle_result *res, int16_t *mfcc_out, uint32_t *scores);

@@ -17,6 +17,13 @@ import os
 import sys
 
 
+def sources_sha(which):
+    """bench.py's kernel_sources_sha: the committed PMC figures carry the sha of the kernel sources they were taken with"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.kernel_sources_sha(which)
+
+
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
@@ -114,7 +121,7 @@ def main():
              "FETCH_SIZE_KB": fs_, "WRITE_SIZE_KB": ws,
              "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM section; the factor 2 was "
                            "re-calibrated for this kernel's access pattern, profiles/r02/VALU_ISSUE.md)",
-             "k_mfcc_hbm_bytes_per_launch": int((2 * fs_ + ws) * 1024)}
+             "k_mfcc_hbm_bytes_per_launch": int((2 * fs_ + ws) * 1024), "kernel_sources_sha": sources_sha("pmc_traffic.json")}
         json.dump(j, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
     # VALU wave-instructions per utterance of the three big kernels (whole-batch launch, B = 65536): bench.py prices
     # a step against the VALU issue ceiling with these
@@ -126,6 +133,7 @@ def main():
         if (k, "SQ_ACTIVE_INST_VALU") in vals:
             vj[k.split("::")[1] + "_valu_slots_per_utt"] = vals[(k, "SQ_ACTIVE_INST_VALU")] / 65536.0
     if len(vj) > 3 and not desc and batch == 65536:
+        vj["kernel_sources_sha"] = sources_sha("pmc_valu.json")
         json.dump(vj, open(os.path.join(here, "pmc_valu.json"), "w"), indent=1)
     open(os.path.join(here, f"{tag}_rocprof_summary.csv"), "w").write("\n".join(out) + "\n")
     print("\n".join(out[-24:]))

@@ -163,10 +163,14 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
         }
         // A segment that starts at sample 1 (only sr_mfcc_batch / sr_recognize_segments callers can produce one: VAD
         // segments start on frame boundaries) puts the first pair of frame 0 at byte offset -2: out of range for the
-        // resource, and the range check is per dword, so x[i-2] AND x[i-1] came back as 0 -- but x[i-1] = sample 0 is the
-        // pre-emphasis predecessor of the segment's first sample (MFCC.C:119).  Wave-uniform and rare: fetch it on its own.
+        // resource, so the load (at least its first dword: x[i-2] AND x[i-1]) came back as 0 -- but x[i-1] = sample 0 is
+        // the pre-emphasis predecessor of the segment's first sample (MFCC.C:119).  Wave-uniform and rare: that lane
+        // fetches its first pair again with plain loads (x[i-2] does not exist and is never used).
         if (it.s0 < 2) {
-            if (off < 0) qa[0] = (uint32_t)it.row[0] << 16;
+            if (off < 0) {
+                qa[0] = (uint32_t)it.row[0] << 16;
+                qb[0] = (uint32_t)it.row[1] | ((uint32_t)it.row[2] << 16);
+            }
         }
         q_item = it_id;
         q_fb = fb;

@@ -78,6 +78,7 @@ struct DtwArgs {
     const int8_t *tie_delta;      // DevTables::tie_delta
     uint32_t tie_g;               // entries of it the workgroup stages in LDS (a multiple of 1024, <= kTieMax)
     uint32_t lds_kc;              // templates per k_dtw_lds workgroup (dtw_lds_pick_u); the store is walked in K / lds_kc chunks
+    uint32_t dp_lanes;            // k_dtw_dp only: lanes per pair of the band kernel (4 / 8 / 16; 0 = default 8; 1 = k_dtw_dp_wave64)
 };
 
 // get_mdl (DTW.C:217-296): P independent pairs

@@ -100,6 +100,7 @@ struct sr_engine {
     DevBuf<uint32_t> tpl_frames_s, tpl_orig;
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
     uint32_t dtw_u = 0, dtw_lds = 0, dtw_tie_g = 0, dtw_kc = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
+    uint32_t dp_lanes = 0;         // sr_set_dp_lanes: lanes per pair of the opt-in full-DP scorer (0 = default)
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
     DevBuf<sr_vad_rec> s_vad;
@@ -580,6 +581,14 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
     return SR_OK;
 }
 
+int sr_set_dp_lanes(sr_engine *h, uint32_t lanes)
+{
+    if (!h) return fail(SR_ERR_BAD_ARG, "null engine");
+    if (lanes != 0 && lanes != 1 && lanes != 4 && lanes != 8 && lanes != 16) return fail(SR_ERR_BAD_ARG, "lanes per pair: 0 (default), 1 (one wave per pair), 4, 8 or 16");
+    h->dp_lanes = lanes;
+    return SR_OK;
+}
+
 int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call)
 {
     if (!h || !launches_per_call) return fail(SR_ERR_BAD_ARG, "null argument");
@@ -675,6 +684,7 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.tie_delta = h->dev.tie_delta;
     a.tie_g = h->dtw_tie_g;
     a.lds_kc = h->dtw_kc;
+    a.dp_lanes = h->dp_lanes;
     return a;
 }
 
@@ -1116,6 +1126,7 @@ int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_i
     if ((size_t)h->tpl_rows * 48 > 150 * 1024) return fail(SR_ERR_BAD_ARG, "templates too long for the LDS-staged DP kernel");
     ENTER_DEVICE(h);
     DtwArgs a = dtw_args(h, d_mfcc, d_vad, d_in_frames, B, d_scores, nullptr);
+    if (!h->tpl_staged_ok) a.tplR = nullptr;  // coefficients beyond +-16383: the band kernel's -2*coef rows do not hold them
     launch_dtw_dp(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SR_OK;

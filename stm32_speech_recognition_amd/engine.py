@@ -210,6 +210,21 @@ class Engine:
                                          _vp(end), _vp(mid), _vp(out), _vp(n)))
         return n, out
 
+    def mfcc_status(self, pcm, start, end, mid):
+        """like mfcc(), with per-record failure instead of a batch error (sr_mfcc_batch_status): returns
+        (frm_num, mfcc, status); a bad record has frm_num 0, an all-zero MFCC record and status != 0."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        B, S = pcm.shape
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32)
+        mid = np.ascontiguousarray(mid, dtype=np.uint32)
+        out = np.zeros((B, self.max_frames, N_COEF), dtype=np.int16)
+        n = np.zeros(B, dtype=np.uint32)
+        st = np.zeros(B, dtype=np.uint32)
+        self._check(self.L.sr_mfcc_batch_status(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B), _vp(start),
+                                                _vp(end), _vp(mid), _vp(out), _vp(n), _vp(st)))
+        return n, out, st
+
     def dtw(self, in_mfcc, in_frames):
         """in_mfcc int16 [B, max_frames, 12] against the template store -> (scores [B,K], results [B])."""
         in_mfcc = np.ascontiguousarray(in_mfcc, dtype=np.int16)
@@ -230,6 +245,21 @@ class Engine:
         sc = np.zeros((B, self.n_templates), dtype=np.uint32)
         self._check(self.L.sr_dtw_dp_batch(self.h, _vp(in_mfcc), _vp(in_frames), C.c_uint32(B), _vp(sc)))
         return sc
+
+    def set_dp_lanes(self, lanes=0):
+        """lanes per pair of the opt-in full-DP scorer: 0 default (8), 4 / 8 / 16 band kernel, 1 = one wave per pair"""
+        self._check(self.L.sr_set_dp_lanes(self.h, C.c_uint32(lanes)))
+
+    def dtw_dp_dev(self, mfcc, scores, in_frames=None, vad=None, stream=None):
+        """OPT-IN non-reference scorer on device tensors: mfcc int16 [B, max_frames, 12], frame counts from in_frames
+        (int32 [B]) or vad records; scores int32 [B, K].  Asynchronous on `stream`."""
+        import torch
+        B = mfcc.shape[0]
+        if stream is None:
+            stream = torch.cuda.current_stream(mfcc.device).cuda_stream
+        self._check(self.L.sr_dtw_dp_batch_dev(self.h, _vp(mfcc), _vp(in_frames), _vp(vad), C.c_uint32(B), _vp(scores),
+                                               C.c_void_p(stream)))
+        return scores
 
     def get_mdl(self, in1, n1, in2, n2, mdl_rows):
         """get_mdl (DTW.C:217-296) on P pairs: in1 int16 [P, rows1, 12], in2 int16 [P, rows2, 12].

@@ -206,6 +206,24 @@ def _oracle_dtw_dp(self, a, na, b, nb):
 Oracle.dtw_dp = _oracle_dtw_dp
 
 
+def _oracle_dtw_dp_batch(self, im, inf, tm, tf, n_threads=8):
+    """all B x K pairs of the NON-REFERENCE full-DP scorer, threaded inside the C library; tf[k] == 0 = invalid slot"""
+    im = np.ascontiguousarray(im, dtype=np.int16)
+    tm = np.ascontiguousarray(tm, dtype=np.int16)
+    inf = np.ascontiguousarray(inf, dtype=np.uint32)
+    tf = np.ascontiguousarray(tf, dtype=np.uint32)
+    B, K = im.shape[0], tm.shape[0]
+    out = np.zeros((B, K), dtype=np.uint32)
+    self.L.sr_oracle_dtw_dp_batch.restype = None
+    self.L.sr_oracle_dtw_dp_batch(_p(im), _p(inf), C.c_uint32(im.shape[1]), C.c_uint32(B), _p(tm), _p(tf),
+                                  C.c_uint32(tm.shape[1]), C.c_uint32(K), C.c_uint32(self.n_coef), _p(out),
+                                  C.c_uint32(n_threads))
+    return out
+
+
+Oracle.dtw_dp_batch = _oracle_dtw_dp_batch
+
+
 def _oracle_delta_mfcc(self, m, n):
     """EXTENSION (own definition, sr_oracle.c): delta cepstra of one record [>= n, n_coef] -> [n, n_coef]."""
     m = np.ascontiguousarray(m, dtype=np.int16)

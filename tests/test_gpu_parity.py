@@ -917,27 +917,175 @@ def test_train_store_matches_reference_layout(golden):
     e.close()
 
 
-def test_dtw_dp_extension_matches_its_oracle():
-    """opt-in NON-REFERENCE full-DP scorer (wavefront across the wave) against its own CPU definition;
-    also sanity: D(a,a) = 0, and DP never exceeds the cost of ANY monotone path it allows (diagonal of equal lengths)"""
+@pytest.mark.parametrize("lanes", [1, 4, 8, 16])
+def test_dtw_dp_extension_matches_its_oracle(lanes):
+    """opt-in NON-REFERENCE full-DP scorer against its own CPU definition, every kernel variant (lanes per pair of the
+    band-limited wavefront; 1 = one wave per pair); also sanity: D(a,a) = 0.  Lengths 1, 2 and around the strip widths,
+    an erased slot, pairs outside the 1/2..2x gate."""
     from stm32_speech_recognition_amd import Engine
     rng = np.random.default_rng(77)
-    maxf, K, B = 150, 9, 24
+    maxf, K, B = 150, 10, 40
     orc = ol.Oracle(max_frames=maxf)
-    tf = np.array([1, 2, 40, 64, 65, 100, 128, 129, 150], np.uint32)
+    tf = np.array([1, 2, 40, 64, 65, 100, 128, 129, 150, 77], np.uint32)
     tm = rng.integers(-2500, 2500, (K, maxf + 1, 12)).astype(np.int16)
+    valid = np.ones(K, np.uint8)
+    valid[9] = 0
     inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
-    inf[:4] = (64, 65, 128, 150)
+    inf[:12] = (64, 65, 128, 150, 1, 2, 3, 4, 7, 8, 9, 17)
     im = rng.integers(-2500, 2500, (B, maxf, 12)).astype(np.int16)
     im[0, :64] = tm[3, :64]  # identical sequence -> score 0
     eng = Engine(max_frames=maxf, device=0)
-    eng.set_templates_dense(tm, tf)
+    eng.set_templates_dense(tm, tf, valid)
+    eng.set_dp_lanes(lanes)
     sc = eng.dtw_dp(im, inf)
-    want = np.array([[orc.dtw_dp(im[b], inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)], dtype=np.uint32)
+    want = orc.dtw_dp_batch(im, inf, tm, np.where(valid != 0, tf, 0))
+    assert np.array_equal(want[3], np.array([orc.dtw_dp(im[3], inf[3], tm[k], tf[k] if valid[k] else 0) for k in range(K)], np.uint32))
     assert np.array_equal(sc, want)
-    assert sc[0, 3] == 0
+    assert sc[0, 3] == 0 and (sc[:, 9] == ol.DIS_ERR).all()
     assert (want == ol.DIS_ERR).sum() > 10 and (want != ol.DIS_ERR).sum() > 40
     eng.close()
+
+
+def test_dtw_dp_full_scale_store_takes_the_generic_kernel():
+    """coefficients beyond +-16383 do not fit the band kernel's -2*coef rows: the store is scored by the one-wave-per-pair
+    kernel, same results as the oracle (u32 wrap of the squared distance included)"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(78)
+    maxf, K, B = 70, 6, 12
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(30, maxf + 1, K).astype(np.uint32)
+    tm = rng.integers(-32768, 32768, (K, maxf + 1, 12)).astype(np.int16)
+    inf = rng.integers(30, maxf + 1, B).astype(np.uint32)
+    im = rng.integers(-32768, 32768, (B, maxf, 12)).astype(np.int16)
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf)
+    assert np.array_equal(eng.dtw_dp(im, inf), orc.dtw_dp_batch(im, inf, tm, tf))
+    eng.close()
+
+
+@pytest.mark.parametrize("lanes,ragged", [(8, False), (8, True), (16, True), (4, False), (1, False)])
+def test_dtw_dp_benchmark_shape_matches_its_oracle(lanes, ragged):
+    """the full-DP scorer at the benchmark's shape: features of 256-frame utterances from the real front end (frame cap
+    320), 100 templates of 192..320 frames with ~10 % outside the 1/2..2x gate (DTW.C:133-137) and one erased slot,
+    96 x 100 = 9 600 pairs; frame counts taken from the VAD records on the device (in_frames == NULL path).  `ragged`:
+    utterances of 100..320 frames, so the groups of a wave walk different bands and finish in different strips."""
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import vad_from_torch
+    rng = np.random.default_rng(91 + lanes + ragged)
+    T, maxf, K, B = 256, 320, 100, 96
+    orc = ol.Oracle(max_frames=maxf)
+    bank = synth.word_bank(10)
+    tfr = [int(v) for v in rng.integers(192, 321, K)]
+    for k in range(0, K, 10):
+        tfr[k] = int(rng.integers(40, 120))  # outside the gate for 256-frame utterances -> dis_err
+    tm, tf = _oracle_templates(orc, bank, tfr, seed=17, S=synth.buf_len_for(320))
+    valid = np.ones(K, np.uint8)
+    valid[7] = 0
+    frames = [int(v) for v in rng.integers(100, 321, B)] if ragged else [T] * B
+    pcm = synth.make_utterances(rng.integers(0, 10, B), frames, seed=19, bank=bank, S=synth.buf_len_for(320), device="cuda:0")
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf, valid)
+    eng.set_dp_lanes(lanes)
+    vad, mfcc = eng.features_dev(pcm)
+    sc = torch.full((B, K), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")
+    eng.dtw_dp_dev(mfcc, sc, vad=vad)
+    torch.cuda.synchronize()
+    vd = vad_from_torch(vad)
+    assert (vd["status"] == 0).all() and np.array_equal(vd["frm_num"], np.array(frames, np.uint32))
+    got = sc.cpu().numpy().view(np.uint32)
+    want = orc.dtw_dp_batch(mfcc.cpu().numpy(), vd["frm_num"], tm, np.where(valid != 0, tf, 0), n_threads=min(32, os.cpu_count() or 8))
+    assert np.array_equal(got, want)
+    assert (want[:, 7] == ol.DIS_ERR).all() and (want != ol.DIS_ERR).sum() > 0.5 * B * K
+    if not ragged:
+        assert (want[:, 0::10] == ol.DIS_ERR).all()
+    eng.close()
+
+
+def test_extension_full_shape_matches_its_oracle():
+    """EXTENSION front end at BASELINE configs[4]'s per-GPU shape (>= 1024 utterances per config): 16 kHz /
+    512-point / 40 Mel, frame cap 320, 256-frame utterances x 500 templates of 192..320 frames with ~10 % outside the
+    1/2..2x gate (DTW.C:133-137), B = 1024.  MFCC s16, all 500 scores u32 and the argmin against the parametrised oracle;
+    the staged DTW kernel must really run its 7 x 125 geometry with the 16 384-entry tie table (squared distances of this
+    front end reach beyond a table that ends at a root of 8 192)."""
+    import ctypes as C
+    from stm32_speech_recognition_amd import Engine, engine
+    from stm32_speech_recognition_amd.engine import results_from_torch, vad_from_torch
+    rng = np.random.default_rng(1640)
+    T, maxf, K, B = 256, 320, 500, 1024
+    geo = (C.c_uint32 * 5)()
+    assert engine.load_library().sr_dtw_geometry(C.c_uint32(K), C.c_uint32(maxf), geo) == 0
+    assert (geo[0], geo[1], geo[2]) == (7, 125, 16384), list(geo)
+    cfg = dict(fs=16000, nfft=512, n_mel=40)
+    orc = ol.Oracle(max_frames=maxf, **cfg)
+    eng = Engine(max_frames=maxf, device=0, **cfg)
+    bank = synth.word_bank(100)
+    tfr = rng.integers(192, 321, K)
+    out_gate = rng.permutation(K)[:K // 10]
+    tfr[out_gate] = rng.integers(60, 128, len(out_gate))  # 2 * frames < 256 -> dis_err for every utterance
+    tpcm = synth.make_utterances(np.arange(K) % 100, tfr, seed=77, bank=bank, S=synth.buf_len_for(320, 2), device="cuda:0", rate=2)
+    tvad, tmf = eng.features_dev(tpcm)
+    torch.cuda.synchronize()
+    tv = vad_from_torch(tvad)
+    assert (tv["status"] == 0).all() and np.array_equal(tv["frm_num"], tfr)
+    tm = np.concatenate([tmf.cpu().numpy(), np.zeros((K, 1, 12), np.int16)], 1)
+    # the template features themselves against the oracle (a strided sample: the batch below covers the front end in full)
+    tp_host = synth.as_u16_numpy(tpcm)
+    for k in range(0, K, 25):
+        rc, a = orc.noise_atap(tp_host[k])
+        seg = orc.vad(tp_host[k], a)
+        n, m = orc.mfcc(tp_host[k], seg[0], seg[1], a)
+        assert n == tfr[k] and np.array_equal(m, tm[k, :n]), k
+    eng.set_templates_dense(tm, tfr.astype(np.uint32))
+    pcm = synth.make_utterances(rng.integers(0, 100, B), [T] * B, seed=1000, bank=bank, S=synth.buf_len_for(T, 2), device="cuda:0", rate=2)
+    out = eng.recognize_dev(pcm, eng.alloc_outputs(B, "cuda:0"))
+    torch.cuda.synchronize()
+    res = results_from_torch(out["results"])
+    tpl = orc.make_templates(tm, tfr.astype(np.uint32))
+    ores, omf, osc = orc.recognize_batch(synth.as_u16_numpy(pcm), tpl, n_threads=min(64, os.cpu_count() or 8))
+    assert (ores["status"] == 0).all() and (ores["frm_num"] == T).all()
+    assert np.array_equal(out["mfcc"].cpu().numpy(), omf)
+    gsc = out["scores"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(gsc, osc)
+    for f in ("best_tpl", "min_dis", "frm_num", "status"):
+        assert np.array_equal(res[f], ores[f]), f
+    assert (osc[:, out_gate] == ol.DIS_ERR).all() and (osc != ol.DIS_ERR).sum() == B * (K - len(out_gate))
+    eng.close()
+
+
+def test_extension_front_end_segments_at_odd_and_first_samples():
+    """EXTENSION frame kernel with caller-chosen segments (sr_mfcc_batch): a segment that starts at sample 1 -- the pair
+    x[-1], x[0] of its first lane lies half outside the capture row, and x[0] is the pre-emphasis predecessor of the
+    segment's first sample (MFCC.C:119) --, odd and even starts, against the oracle; plus per-record failure
+    (sr_mfcc_batch_status): a segment outside the buffer, one shorter than a frame and one longer than the cap among good ones."""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(5)
+    for cfg, fl, hop in ((dict(fs=16000, nfft=512, n_mel=40), 320, 160), ({}, 160, 80)):
+        maxf = 40
+        orc = ol.Oracle(max_frames=maxf, **cfg)
+        eng = Engine(max_frames=maxf, device=0, **cfg)
+        S = 16000
+        B = 12
+        pcm = (2048 + rng.integers(-900, 900, (B, S))).astype(np.uint16)
+        starts = np.array([1, 1, 2, 3, 4, 5, 161, 7777, 1, 100, 50, 200], np.int32)
+        nfr = np.array([1, 17, 33, 5, 8, 9, 12, 30, 40, 3, 2, 6], np.int32)
+        ends = starts + fl + hop * (nfr - 1) + rng.integers(0, hop, B).astype(np.int32)
+        mid = rng.integers(1900, 2200, B).astype(np.uint32)
+        # bad records among the good ones
+        starts[9], ends[9] = 0, 4000            # start < 1: the reference would read before the buffer
+        ends[10] = starts[10] + fl - 1          # shorter than a frame
+        ends[11] = starts[11] + fl + hop * maxf  # maxf + 1 frames
+        n, mf, st = eng.mfcc_status(pcm, starts, ends, mid)
+        assert st.tolist() == [0] * 9 + [ol.ST_SEG_OOB, ol.ST_MFCC_FAIL, ol.ST_MFCC_FAIL]
+        assert n[9:].tolist() == [0, 0, 0] and not mf[9:].any()
+        wrong = []
+        for b in range(9):
+            a = ol.Atap(int(mid[b]), 0, 0, 0)
+            nn, m = orc.mfcc(pcm[b], int(starts[b]), int(ends[b]), a)
+            assert nn == n[b] == nfr[b], (b, nn, n[b])
+            if not np.array_equal(mf[b, :nn], m) or mf[b, nn:].any():
+                wrong.append((b, int(starts[b]), [int(f) for f in np.nonzero((mf[b, :nn] != m).any(1))[0][:6]]))
+        assert not wrong, (cfg, wrong)  # (record, start sample, first differing frames)
+        eng.close()
 
 
 def test_extension_front_end_matches_its_oracle():
