@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the extra N = 1 measurements of configs[1] and configs[4] (other_configs)")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each other_configs entry")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the contract's N = 1/2/4/8 runs): --batch utterances PER GPU; strong: --batch is the "
+                         "GLOBAL batch, split evenly over the GPUs (e.g. --batch 524288 = BASELINE configs[3] at every N)")
     ap.add_argument("--scorer", choices=["greedy", "dp"], default="greedy",
                     help="greedy = the reference's dtw() (the metric); dp = time ONLY the opt-in NON-REFERENCE full-DP scorer "
                          "(sr_dtw_dp_batch_dev) on the same features -- a side measurement, never the headline metric")
@@ -176,6 +179,56 @@ def make_templates(eng, bank, Kt, n_words, rate, dev):
     return tm, tfr, rng
 
 
+class ClockSampler:
+    """shader clock during the timed region, from sysfs (/sys/class/drm/card*/device/pp_dpm_sclk: the line marked `*` is
+    the current level; on MI300-class parts level 1 carries the live frequency).  Sampled every 20 ms on a host thread;
+    with several cards visible in sysfs the busiest one (highest clock) of each sample is taken -- the container exposes
+    one GPU to HIP but sysfs may list the whole node.  None when sysfs is not readable."""
+
+    def __init__(self, period=0.02):
+        import glob
+        import threading
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.files else None
+
+    def _read(self):
+        best = None
+        for f in self.files:
+            try:
+                for ln in open(f).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        mhz = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                        best = mhz if best is None or mhz > best else best
+            except Exception:
+                pass
+        return best
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self._th:
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._th:
+            self._th.join(timeout=1)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        a = np.array(self.samples)
+        return {"mean_mhz": float(a.mean()), "min_mhz": float(a.min()), "max_mhz": float(a.max()), "samples": int(a.size),
+                "source": "sysfs pp_dpm_sclk, 20 ms period, during the timed steps"}
+
+
 FORCE_DIST = False  # test hook SR_BENCH_FORCE_DIST=1: initialise the process group and run the exchange even at N = 1
 
 
@@ -223,16 +276,46 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    finish()  # every step's kernels AND its all-gather are complete
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    with ClockSampler() as clk:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        finish()  # every step's kernels AND its all-gather are complete
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    dt_rank = dt
     dt = du.max_over_ranks(dt, dev, 2 if (use_dist and world == 1) else world)
     stage = eng.stage_ms()  # hipEvent timings of the timed steps, each kernel on the stream it was launched on
     eng.set_profiling(False)
+    exchange = None
+    if use_dist:
+        # diagnostics of the path's one exchange step (outside the timed region): every rank's own wall time of the timed
+        # steps, the all-gather ALONE on an otherwise idle GPU (hipEvents on the current stream around a synchronous
+        # call: the stream waits for the collective), and how much of it a step does not hide behind the next step's
+        # kernels (wall time per step minus the fork -> join time of the engine's kernels; includes host launch gaps)
+        per_rank = du.gather_floats(dt_rank / steps * 1e3, dev, world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ag = []
+        for _ in range(3):
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0.record()
+            dist.all_gather_into_tensor(xchg.gathered[0], outs[0]["scores"].contiguous())
+            e1.record()
+            torch.cuda.synchronize()
+            ag.append(e0.elapsed_time(e1))
+        exchange = {"backend": dist.get_backend(), "ranks_in_communicator": dist.get_world_size(),
+                    "step_ms_per_rank": per_rank, "allgather_ms": float(np.median(ag)),
+                    "allgather_bytes_per_rank_out": int(world * B * Kt * 4),
+                    "exposed_allgather_ms": max(0.0, dt / steps * 1e3 - stage["total"]),
+                    "note": "allgather_ms: the collective alone (idle GPU, median of 3); exposed: wall time per step minus the "
+                            "engine's fork->join kernel time of a step = what the double-buffered exchange does not hide "
+                            "(upper bound: includes host launch gaps)"}
+        try:
+            exchange["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
     # untimed extra: the same step as ONE chunk on one stream, for the per-kernel durations without overlap
     eng.set_pipeline(streams=1)
     eng.set_profiling(True)
@@ -250,7 +333,7 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
         g = xchg.gathered[0][rank * B:(rank + 1) * B]
         assert torch.equal(g, out["scores"]), "all-gather did not return this rank's shard in place"
     return dict(dt=dt, stage=stage, stage_iso=stage_iso, acc=acc, eng=eng, pcm=pcm, out=out, tm=tm, tfr=tfr, S=S, rate=rate,
-                eng_cfg=eng_cfg, K=Kt, n_words=n_words)
+                eng_cfg=eng_cfg, K=Kt, n_words=n_words, sclk=clk.summary(), exchange=exchange)
 
 
 def workload_name(workload, B, Kt):
@@ -475,6 +558,13 @@ def latency_block(local_rank, n_utt=64):
         t = us(f_dev, 50)
         out[f"sr_recognize_batch_dev_B{Bs}_us"] = t
         out[f"sr_recognize_batch_dev_B{Bs}_us_per_utterance"] = t / Bs
+        # where the time goes: hipEvents around each of the call's four kernels (the events themselves add a few us)
+        eng.set_profiling(True)
+        for i in range(20):
+            f_dev(i)
+        sm = eng.stage_ms()
+        eng.set_profiling(False)
+        out[f"sr_recognize_batch_dev_B{Bs}_kernel_us"] = {k: sm[k] * 1e3 for k in ("vad", "mfcc", "dtw", "argmin", "total")}
     eng.close()
     return out
 
@@ -525,6 +615,11 @@ def run_rank(args):
         du.init_process_group(backend, local_rank)
     torch.cuda.set_device(local_rank)
     B = args.batch
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"--scaling strong: the global batch {B} must divide over {world} GPUs")
+        B = B // world  # this rank's shard of the fixed global batch
+        args.batch_global, args.batch = args.batch, B
     if args.scorer == "dp":
         if world != 1 or args.workload != "ref":
             raise SystemExit("--scorer dp is a single-GPU side measurement of the reference workload")
@@ -635,9 +730,13 @@ def headline(args, m, world, backend="nccl", launcher=None):
             slots = sum(v for k, v in vj.items() if k.endswith("_valu_slots_per_utt")) or insts
             peak = 1024 * 2.4e9 / 4.0
             achv = slots * B / (stage["total"] * 1e-3)
+            sclk = m.get("sclk")
             roofline_valu = {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "4-cycle issue slots/s",
                              "frac": achv / peak, "valu_slots_per_utt": slots, "valu_insts_per_utt": insts,
-                             "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9, "source": vj.get("source"),
+                             "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9,
+                             "clock_hz_measured": sclk["mean_mhz"] * 1e6 if sclk else None,
+                             "frac_at_measured_clock": achv / (1024 * sclk["mean_mhz"] * 1e6 / 4.0) if sclk else None,
+                             "source": vj.get("source"),
                              "rates_source": "profiles/r02/VALU_ISSUE.md (per-opcode s_memtime micro-benchmark)",
                              "note": "derived: slot counts from the committed PMC pass x this run's step time; the chip "
                                      "clocks 2.3-2.4 GHz under this load, the ceiling assumes the nominal 2.4"}
@@ -656,11 +755,13 @@ def headline(args, m, world, backend="nccl", launcher=None):
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": getattr(args, "scaling", "weak"),
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
-        "config": {"workload": workload_name(args.workload, B, Kt),
+        "exchange": m.get("exchange"),
+        "config": {"workload": workload_name(args.workload, B, Kt) + (f" (strong scaling: global batch {args.batch_global})"
+                                                                       if getattr(args, "batch_global", None) else ""),
                    "batch_per_gpu": B, "templates": Kt, "frames": T, "buf_len": S, "parallelism": par},
         # HBM roofline of the dominant kernel, as the contract defines it: algorithmic bytes of one launch / the duration
         # of that launch.  achieved / frac = the kernel ALONE on the chip, one launch over the whole batch (hipEvents on
@@ -688,6 +789,7 @@ def headline(args, m, world, backend="nccl", launcher=None):
         "kernel_ms": stage,
         "kernel_ms_isolated": {**stage_iso, "note": "untimed extra pass: whole batch as one chunk on one stream (no overlap)"},
         "top1_word_accuracy": m["acc"],
+        "sclk": m.get("sclk"),
     }
     if launcher:
         line["launcher"] = launcher
@@ -704,8 +806,10 @@ def run_single_process(args):
     if args.workload != "ref":
         raise SystemExit("--launcher single runs the reference workload only")
     devs = list(range(n))
-    if "SR_BENCH_DEVICE" in os.environ:  # test hook: all "ranks" on one device (needs SR_MULTI_TEST_ALLOW_DUP=1 + the fake RCCL)
+    if "SR_BENCH_DEVICE" in os.environ:  # test hook: all "ranks" on one device (needs the fake RCCL named by SR_RCCL_LIBRARY)
         devs = [int(os.environ["SR_BENCH_DEVICE"])] * n
+        from stm32_speech_recognition_amd.engine import dev_hook
+        dev_hook("multi_allow_dup", 1)
     if not torch.cuda.is_available() or max(devs) >= torch.cuda.device_count():
         raise SystemExit(f"--gpus {n} but {torch.cuda.device_count()} MI355X visible (there is no CPU path)")
     rate, eng_cfg, Kt, n_words = workload_setup("ref", args.templates)

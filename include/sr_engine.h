@@ -110,9 +110,12 @@ typedef struct sr_tables {
     int16_t *tw_kr;     /* [1020]            first  DCW column of the ST coefficient table, in table order */
     int16_t *tw_ki;     /* [1020]            second DCW column */
     uint32_t *log_thr;  /* [2220]            log_thr[m] = min{n : (u32)(log((double)n)*100) >= m} (host libm), [2219] = sentinel */
-    int8_t *tie_delta;  /* [32768]           DTW.C:59,156-184: T(g) = g*(g+2) + tie_delta[g] = min{d : (u32)sqrtf((float)d) >= g + 1} */
-} sr_tables;
+} sr_tables; /* layout frozen (eight pointers): further tables get their own entry point, like sr_build_tie_table below, so a
+              * caller compiled against an older header never hands over a shorter struct than the library reads */
 int sr_build_tables(const sr_config *cfg, const sr_tables *out);
+/* Host-only: the tie-threshold table of the staged DTW kernel, out[32768]:
+ * DTW.C:59,156-184: T(g) = g*(g+2) + out[g] = min{d : (u32)sqrtf((float)d) >= g + 1}  (independent of the front end) */
+int sr_build_tie_table(int8_t *out);
 /* The log step table is built with the run-time host's libm `log` -- the expression MFCC.C:168 evaluates -- and compared with
  * the positions the library ships (csrc/sr_log_thr_ref.inc: the libm the golden fixtures were generated with).  If they
  * differ (a libm whose log is off in the last bit at an integer crossing of log(n)*100) the SHIPPED table is used, sr_create
@@ -251,11 +254,12 @@ int sr_multi_recognize(sr_multi *m, const uint16_t *pcm, uint64_t pcm_stride, ui
 int sr_allgather_scores(void *nccl_comm, const uint32_t *d_scores, uint32_t *d_all, uint64_t count, void *stream);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
- * sr_recognize_batch_dev cuts a large batch into chunks (at least SR_PIPE_MIN_CHUNK = 4096 utterances each, at most
- * SR_PIPE_MAX_CHUNKS = 12) and runs them on SR_PIPE_STREAMS = 3 (max 4) internal streams forked from / joined to the
- * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap (environment
- * variables read by sr_create; SR_PIPE_STREAMS=1 keeps everything on the caller's stream).  SR_MFCC_GRID overrides the
- * number of workgroups of the frame kernel (default: four times the workgroups resident at once).
+ * sr_recognize_batch_dev cuts a large batch into chunks (at least min_chunk = 4096 utterances each, at most
+ * max_chunks = 12) and runs them on streams = 3 (max 4) internal streams forked from / joined to the
+ * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap
+ * (sr_set_pipeline changes the three numbers; streams = 1 keeps everything on the caller's stream).  The library reads
+ * no tuning knob from the environment (the only environment variable it honours is SR_RCCL_LIBRARY, the path of the
+ * collective library).
  * With profiling on, every kernel launch is bracketed with hipEvents on the stream it is launched on;
  * sr_get_stage_ms synchronises and returns, averaged over everything recorded since sr_set_profiling(h, 1):
  * ms[0] VAD, ms[1] MFCC (frame kernel), ms[2] DTW, ms[3] argmin = duration of ONE launch of that kernel (under
@@ -265,6 +269,17 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
 int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);
+
+/* Development and test hooks -- NOT part of the production surface.  Process-global integer knobs, 0 = default:
+ *   "dtw_u", "dtw_tie_g", "dtw_kc"   force the staged DTW kernel's workgroup geometry (read when a template store is set;
+ *                                    a forced combination that does not fit the LDS / the grid is ignored)
+ *   "mfcc_grid"                      workgroups of the frame kernel (read by sr_create)
+ *   "dtw_debug"                      print the DTW geometry when a store is set
+ *   "perturb_log_thr", "log_thr_from_host"   exercise / bypass the shipped log-step-table check (sr_log_table_mismatches)
+ *   "multi_allow_dup"                sr_multi_create accepts one device several times; honoured only when SR_RCCL_LIBRARY
+ *                                    names the collective library explicitly (1-GPU tests over the in-process RCCL double)
+ * Unknown names return SR_ERR_BAD_ARG. */
+int sr_dev_hook(const char *name, int64_t value);
 
 /* diagnostics, host-only (touches no device): the launch geometry the staged DTW kernel would use for a store of n_templates
  * and a frame cap of max_frames: out[0] = utterances per workgroup (0 = generic kernel), out[1] = templates per workgroup (the

@@ -473,14 +473,17 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint
     auto blocks_for = [](size_t lds) { return (uint32_t)(kCuLds / ((lds + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); };
     uint32_t best_u = 0, best_g = 0, best_kc = 0;
     double best = 0;
-    const char *force = getenv("SR_DTW_U");  // tuning overrides
-    const char *force_g = getenv("SR_DTW_TIE_G");
-    const char *force_kc = getenv("SR_DTW_KC");
+    // development hooks (sr_dev_hook): force U / the table size / cap the templates per workgroup.  A forced combination
+    // that does not fit the CU's LDS or the grid is skipped like any other candidate (the generic kernel serves the store
+    // if nothing fits).
+    const uint32_t force = (uint32_t)dev_hook(kHookDtwU), force_g = (uint32_t)dev_hook(kHookDtwTieG),
+                   force_kc = (uint32_t)dev_hook(kHookDtwKc);
     for (uint32_t U = 1; U <= (uint32_t)kDtwMaxU; U++) {
         uint32_t kc = K < 1024u / U ? K : 1024u / U;  // lanes of a workgroup
-        if (force_kc && atoi(force_kc) >= 1 && (uint32_t)atoi(force_kc) < kc) kc = (uint32_t)atoi(force_kc);
+        if (force_kc >= 1 && force_kc < kc) kc = force_kc;
         if (!kc) break;
         const uint32_t chunks = (K + kc - 1) / kc;
+        if (chunks > 65535) continue;               // the chunks are the grid's second dimension
         kc = (K + chunks - 1) / chunks;             // equal chunks
         const uint64_t pairs = (uint64_t)U * kc;
         const size_t lds = dtw_lds_fixed(U, max_frames);
@@ -492,7 +495,10 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint
         if (blocks < 1) continue;
         uint32_t g = kMinTie;  // the largest table that does not cost a resident workgroup
         while (g < (uint32_t)kTieMax && blocks_for(lds + 2 * g) >= blocks) g *= 2;
-        if (force_g && atoi(force_g) >= (int)kMinTie && atoi(force_g) <= kTieMax) g = (uint32_t)atoi(force_g) & ~1023u;
+        if (force_g >= kMinTie && force_g <= (uint32_t)kTieMax) {
+            g = force_g & ~1023u;
+            if (blocks_for(lds + g) < 1) continue;  // a forced table that does not fit beside the utterances
+        }
         const double eff = (double)K / ((double)chunks * 64.0 * waves / U);  // lanes that carry a pair, over all chunks
         const double resident = (double)(blocks * waves);
         // lanes per template row: worth more the larger the store (at K = 100 five utterances x 100 templates in three
@@ -503,7 +509,7 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint
         const double cover = g >= 16384 ? 1.0 : g >= 8192 ? 0.98 : 0.9;
         const double share = (1.0 - w / U) * (1.0 - 0.005 * (chunks - 1)) * cover;
         double score = eff * (resident >= 24 ? 1.0 : resident / 24.0) * share;
-        if (force && (uint32_t)atoi(force) == U) score = 100.0;
+        if (force && force == U) score = 100.0;
         if (score > best + 1e-9) {
             best = score;
             best_u = U;

@@ -8,6 +8,22 @@
 
 namespace sr {
 
+// Development / test hooks (C ABI: sr_dev_hook): process-global integer knobs, 0 = default behaviour.  They replace the
+// environment variables earlier rounds read inside the library: nothing in the product depends on the environment any
+// more, except SR_RCCL_LIBRARY (the path of the collective library, a deployment setting).
+enum DevHook {
+    kHookDtwU,            // "dtw_u":       force U utterances per k_dtw_lds workgroup (read when a template store is set)
+    kHookDtwTieG,         // "dtw_tie_g":   force the staged tie-table size
+    kHookDtwKc,           // "dtw_kc":      cap the templates per k_dtw_lds workgroup
+    kHookMfccGrid,        // "mfcc_grid":   workgroups of the frame kernel (read by sr_create)
+    kHookPerturbLogThr,   // "perturb_log_thr": move host-built log step m by one (exercises the shipped-table check)
+    kHookLogThrFromHost,  // "log_thr_from_host": keep the host's log step table even where it differs from the shipped one
+    kHookMultiAllowDup,   // "multi_allow_dup": sr_multi_create accepts one device several times (1-GPU tests over the RCCL double)
+    kHookDtwDebug,        // "dtw_debug":   print the k_dtw_lds geometry when a store is set
+    kHookCount
+};
+int64_t dev_hook(DevHook h);
+
 // device-resident constant tables (see sr_tables.h)
 struct DevTables {
     const uint16_t *hamm;      // [160]

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,11 @@ static int fail(int code, const std::string &msg)
     return code;
 }
 int set_error(int code, const std::string &msg) { return fail(code, msg); }  // for the other translation units
+
+static std::atomic<int64_t> g_hooks[kHookCount];
+int64_t dev_hook(DevHook h) { return g_hooks[h].load(std::memory_order_relaxed); }
+static const char *const kHookNames[kHookCount] = {"dtw_u", "dtw_tie_g", "dtw_kc", "mfcc_grid", "perturb_log_thr",
+                                                   "log_thr_from_host", "multi_allow_dup", "dtw_debug"};
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -184,6 +190,17 @@ static int front_end_of(const sr_config *cfg, FrontEnd *fe)
 
 int sr_log_table_mismatches(void) { return log_table_mismatches(); }
 
+int sr_dev_hook(const char *name, int64_t value)
+{
+    if (!name) return fail(SR_ERR_BAD_ARG, "null hook name");
+    for (int i = 0; i < kHookCount; i++)
+        if (std::strcmp(name, kHookNames[i]) == 0) {
+            g_hooks[i].store(value, std::memory_order_relaxed);
+            return SR_OK;
+        }
+    return fail(SR_ERR_BAD_ARG, std::string("unknown development hook: ") + name);
+}
+
 int sr_dtw_geometry(uint32_t n_templates, uint32_t max_frames, uint32_t out[5])
 {
     if (!out || !n_templates || max_frames < 2 || max_frames > 16383) return fail(SR_ERR_BAD_ARG, "null / zero argument");
@@ -230,10 +247,16 @@ int sr_build_tables(const sr_config *cfg, const sr_tables *out)
     if (out->tw_kr) std::memcpy(out->tw_kr, t.tw_kr.data(), t.tw_kr.size() * 2);
     if (out->tw_ki) std::memcpy(out->tw_ki, t.tw_ki.data(), t.tw_ki.size() * 2);
     if (out->log_thr) std::memcpy(out->log_thr, t.log_thr.data(), t.log_thr.size() * 4);
-    if (out->tie_delta) {
-        if (t.tie_delta.size() != (size_t)kTieMax) return fail(SR_ERR_BAD_CONFIG, "internal: DTW tie-threshold table does not fit 8 bits");
-        std::memcpy(out->tie_delta, t.tie_delta.data(), t.tie_delta.size());
-    }
+    return SR_OK;
+}
+
+int sr_build_tie_table(int8_t *out)
+{
+    if (!out) return fail(SR_ERR_BAD_ARG, "null argument");
+    HostTables t;
+    build_tables(t, kFrontRef);  // the tie thresholds do not depend on the front end
+    if (t.tie_delta.size() != (size_t)kTieMax) return fail(SR_ERR_BAD_CONFIG, "internal: DTW tie-threshold table does not fit 8 bits");
+    std::memcpy(out, t.tie_delta.data(), t.tie_delta.size());
     return SR_OK;
 }
 
@@ -261,17 +284,6 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->atap_frm = atap_frm;
     h->frame_len = (uint32_t)fe.frame_len;
     h->hop = (uint32_t)fe.hop;
-    {
-        auto env_u32 = [](const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
-            const char *v = getenv(name);
-            if (!v || !*v) return dflt;
-            const long x = atol(v);
-            return (uint32_t)(x < (long)lo ? lo : (x > (long)hi ? hi : x));
-        };
-        h->pipe_streams = env_u32("SR_PIPE_STREAMS", 3, 1, sr_engine::kPipeStreams);
-        h->pipe_min_chunk = env_u32("SR_PIPE_MIN_CHUNK", 4096, 1, 1u << 30);
-        h->pipe_max_chunks = env_u32("SR_PIPE_MAX_CHUNKS", 12, 1, 64);
-    }
     h->mfcc_tile = mfcc_frames_per_tile(h->frame_len);
     // Grid of the frame kernel: FOUR times the workgroups that are resident at once, work items strided.  Exactly the
     // resident set (one persistent wave of workgroups) left ~15 % of the kernel's own time to stragglers: the workgroups
@@ -279,9 +291,8 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     // on the chip, 65 536 x 256 frames: 1024 workgroups 19.0 ms, 2048 17.8, 4096 17.1, 16 384 16.6; the per-workgroup
     // set-up -- coefficient and DCT tables -- is amortised over 80 items at 4096).
     h->mfcc_grid_cap = 4 * mfcc_resident_workgroups(h->frame_len);
-    if (const char *gv = getenv("SR_MFCC_GRID")) {  // tuning override: workgroups of the frame kernel
-        const long x = atol(gv);
-        if (x > 0) h->mfcc_grid_cap = (uint32_t)x;
+    if (const int64_t gv = dev_hook(kHookMfccGrid)) {  // development hook: workgroups of the frame kernel
+        if (gv > 0) h->mfcc_grid_cap = (uint32_t)gv;
     }
     build_tables(h->host, fe);
     warn_log_table();
@@ -464,8 +475,7 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
         h->dtw_lds = (uint32_t)lds;
         h->dtw_tie_g = tie_g;
         h->dtw_kc = kc;
-        if (const char *dbg = getenv("SR_DTW_DEBUG"))
-            if (dbg[0] == '1')
+        if (dev_hook(kHookDtwDebug))
                 std::fprintf(stderr, "sr_engine: k_dtw_lds geometry for K = %u, %u rows: U = %u, Kc = %u, tie table %u, LDS %zu bytes\n", K,
                              h->cfg.max_frames, h->dtw_u, kc, tie_g, lds);
     }

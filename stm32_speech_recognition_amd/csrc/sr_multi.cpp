@@ -154,10 +154,11 @@ int sr_multi_create(const sr_config *cfg, const int *devices, uint32_t n_dev, sr
 {
     if (!cfg || !devices || !out || n_dev == 0 || n_dev > 64) return set_error(SR_ERR_BAD_ARG, "null argument / device count 1..64");
     *out = nullptr;
-    // SR_MULTI_TEST_ALLOW_DUP=1 (tests only): several "ranks" on one device, so that the N > 1 bookkeeping can be
-    // executed on a 1-GPU box against the in-process collective double (a real RCCL refuses duplicate devices itself)
-    const char *dup = getenv("SR_MULTI_TEST_ALLOW_DUP");
-    if (!(dup && dup[0] == '1'))
+    // development hook "multi_allow_dup" (tests only): several "ranks" on one device, so that the N > 1 bookkeeping can be
+    // executed on a 1-GPU box against the in-process collective double.  Honoured only together with an explicitly named
+    // collective library (SR_RCCL_LIBRARY): a real RCCL errors or hangs on duplicate devices.
+    const bool allow_dup = sr::dev_hook(sr::kHookMultiAllowDup) != 0 && getenv("SR_RCCL_LIBRARY") != nullptr;
+    if (!allow_dup)
         for (uint32_t i = 0; i < n_dev; i++)
             for (uint32_t j = 0; j < i; j++)
                 if (devices[i] == devices[j]) return set_error(SR_ERR_BAD_ARG, "duplicate device ordinal");

@@ -1,5 +1,7 @@
+#include "sr_device.h"
 #include "sr_tables.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,8 +13,8 @@ namespace sr {
 static const uint32_t kLogThrRef[kLogMax + 2] = {
 #include "sr_log_thr_ref.inc"
 };
-static int g_log_mismatches = 0;
-int log_table_mismatches() { return g_log_mismatches; }
+static std::atomic<int> g_log_mismatches{0};
+int log_table_mismatches() { return g_log_mismatches.load(); }
 
 // Matlab int32(): round half away from zero.
 static double mround(double v) { return v >= 0.0 ? std::floor(v + 0.5) : -std::floor(-v + 0.5); }
@@ -144,17 +146,18 @@ static void gen_log_thr(HostTables &t)
     // difference at one of the 2219 integer crossings of log(n)*100 would move a step by one n.  The positions found with
     // THIS host's libm are compared with the shipped ones (the libm the golden fixtures were made with): on a mismatch the
     // shipped table is used -- results then equal the fixtures', not this host's C path -- and the count is kept for
-    // sr_log_table_mismatches() / the warning of sr_create.  SR_LOG_THR_FROM_HOST=1 keeps the host's table (used to
-    // regenerate the .inc); SR_TEST_PERTURB_LOG_THR=m (tests) moves the host-built entry m by one to exercise the check.
-    if (const char *pv = getenv("SR_TEST_PERTURB_LOG_THR")) {
-        const int m = atoi(pv);
+    // sr_log_table_mismatches() / the warning of sr_create.  Development hooks (sr_dev_hook): "log_thr_from_host" keeps the
+    // host's table (used to regenerate the .inc); "perturb_log_thr" = m (tests) moves the host-built entry m by one to
+    // exercise the check.
+    {
+        const int64_t m = dev_hook(kHookPerturbLogThr);
         if (m >= 1 && m <= kLogMax) t.log_thr[m] += 1;
     }
-    const char *keep = getenv("SR_LOG_THR_FROM_HOST");
+    const bool keep = dev_hook(kHookLogThrFromHost) != 0;
     int bad = 0;
     for (int m = 0; m <= kLogMax + 1; m++) bad += t.log_thr[m] != kLogThrRef[m];
-    g_log_mismatches = bad;
-    if (bad && !(keep && keep[0] == '1')) t.log_thr.assign(kLogThrRef, kLogThrRef + kLogMax + 2);
+    g_log_mismatches.store(bad);
+    if (bad && !keep) t.log_thr.assign(kLogThrRef, kLogThrRef + kLogMax + 2);
 }
 
 // DTW.C:59 takes (u32)sqrtf((float)d) of a u32 sum of squares.  The root function g is monotone; the staged DTW kernel

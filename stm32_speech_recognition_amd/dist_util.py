@@ -88,6 +88,17 @@ def max_over_ranks(value, device, world):
     return float(t.item())
 
 
+def gather_floats(value, device, world):
+    """one float per rank -> list of all ranks' values, in rank order (diagnostics: per-rank step times)"""
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    n = dist.get_world_size()
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = torch.empty(n, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, t)
+    return [float(v) for v in out.cpu()]
+
+
 def argmin_first(scores):
     """Strict-< scan in slot order (main.c:285): first minimum wins, all dis_err -> slot 0.
     scores: int32 tensor holding u32 bit patterns."""

@@ -63,8 +63,16 @@ def _vp(x):
     return C.c_void_p(x.data_ptr())
 
 
+def dev_hook(name, value):
+    """sr_dev_hook: development / test knobs of the library (process-global, 0 = default); see include/sr_engine.h"""
+    L = load_library()
+    rc = L.sr_dev_hook(name.encode(), C.c_int64(value))
+    if rc != 0:
+        raise SrError(f"sr_dev_hook error {rc}: {L.sr_last_error().decode()}")
+
+
 class _Tables(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("hamm", "tri_cen", "tri_even", "tri_odd", "dct", "tw_kr", "tw_ki", "log_thr", "tie_delta")]
+    _fields_ = [(n, C.c_void_p) for n in ("hamm", "tri_cen", "tri_even", "tri_odd", "dct", "tw_kr", "tw_ki", "log_thr")]
 
 
 def build_tables(**kw):
@@ -79,11 +87,15 @@ def build_tables(**kw):
     out = dict(hamm=np.zeros(frame_len, np.uint16), tri_cen=np.zeros(cfg.n_mel, np.uint16),
                tri_even=np.zeros(nb, np.uint16), tri_odd=np.zeros(nb, np.uint16),
                dct=np.zeros(cfg.n_coef * cfg.n_mel, np.int8), tw_kr=np.zeros(1020, np.int16),
-               tw_ki=np.zeros(1020, np.int16), log_thr=np.zeros(2220, np.uint32), tie_delta=np.zeros(32768, np.int8))
+               tw_ki=np.zeros(1020, np.int16), log_thr=np.zeros(2220, np.uint32))
     t = _Tables(**{k: v.ctypes.data_as(C.c_void_p) for k, v in out.items()})
     rc = L.sr_build_tables(C.byref(cfg), C.byref(t))
     if rc != 0:
         raise SrError(f"sr_build_tables error {rc}: {L.sr_last_error().decode()}")
+    out["tie_delta"] = np.zeros(32768, np.int8)  # front-end independent: its own entry point
+    rc = L.sr_build_tie_table(out["tie_delta"].ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise SrError(f"sr_build_tie_table error {rc}: {L.sr_last_error().decode()}")
     return out
 
 

@@ -3,8 +3,8 @@ the score matrix == the single-engine answer, through the host-buffer call and t
 
 Importable (tests/test_gpu_parity.py) and runnable:  python tests/multi_case.py 0,0,0 37
 The script form exists for the fake-RCCL runs: csrc/sr_multi.cpp binds its collective library once per process, so a run
-against tests/fake_rccl/librccl.so.1 (SR_RCCL_LIBRARY) with several ranks on device 0 (SR_MULTI_TEST_ALLOW_DUP=1) needs a
-process of its own."""
+against tests/fake_rccl/librccl.so.1 (SR_RCCL_LIBRARY) with several ranks on device 0 (development hook
+"multi_allow_dup", switched on here when the device list holds duplicates) needs a process of its own."""
 import ctypes as C
 import json
 import os
@@ -77,6 +77,9 @@ if __name__ == "__main__":
         if p not in sys.path:
             sys.path.insert(0, p)
     devs = [int(x) for x in sys.argv[1].split(",")]
+    if len(set(devs)) < len(devs):
+        from stm32_speech_recognition_amd.engine import dev_hook
+        dev_hook("multi_allow_dup", 1)
     Bs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [37]
     g = np.load(os.path.join(HERE, "golden", "ref_golden.npz"))
     out = [multi_case(devs, g, B) for B in Bs]

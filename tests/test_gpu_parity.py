@@ -200,12 +200,11 @@ def test_full_path_matches_oracle(T, B, K):
     eng.close()
 
 
-def test_chunked_multi_stream_pipeline_matches_oracle(monkeypatch):
+def test_chunked_multi_stream_pipeline_matches_oracle():
     """sr_recognize_batch_dev cuts large batches into chunks on internal streams; force that path at a small batch
     (8 chunks of 96 utterances over 4 streams, ragged last chunk) and compare everything with the oracle"""
     from stm32_speech_recognition_amd import Engine
     from stm32_speech_recognition_amd.engine import results_from_torch
-    monkeypatch.setenv("SR_PIPE_MIN_CHUNK", "96")
     T, B, K = 119, 8 * 96 + 5, 10
     bank = synth.word_bank(8)
     orc = ol.Oracle(max_frames=T)
@@ -217,6 +216,7 @@ def test_chunked_multi_stream_pipeline_matches_oracle(monkeypatch):
     pcm = synth.as_u16_numpy(pcm_t)
     pcm[5] = 2048  # a capture with no speech at all -> VAD fail in the middle of a chunk
     eng = Engine(max_frames=T, device=0)
+    eng.set_pipeline(streams=3, min_chunk=96, max_chunks=12)
     eng.set_templates_dense(tm, tf)
     dev = torch.device("cuda", 0)
     out = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
@@ -230,7 +230,7 @@ def test_chunked_multi_stream_pipeline_matches_oracle(monkeypatch):
     side.synchronize()
     st = eng.stage_ms()
     eng.set_profiling(False)
-    assert st["launches_per_call"] == 8 and st["total"] > 0  # 773 // 96 = 8 chunks (< SR_PIPE_MAX_CHUNKS)
+    assert st["launches_per_call"] == 8 and st["total"] > 0  # 773 // 96 = 8 chunks (< max_chunks)
     tpl = orc.make_templates(tm, tf)
     ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
     res = results_from_torch(res_t)
@@ -333,11 +333,8 @@ def test_random_shapes_match_oracle(seed, maxf, K):
     pcm = synth.as_u16_numpy(pcm_t)
     for b in rng.integers(0, B, max(1, B // 20)):
         pcm[b] = 2048 + (b % 3)                                # silent captures -> VAD fail
-    os.environ["SR_PIPE_MIN_CHUNK"] = str(int(rng.choice([7, 64, 4096])))
-    try:
-        eng = Engine(max_frames=maxf, device=0)
-    finally:
-        del os.environ["SR_PIPE_MIN_CHUNK"]
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_pipeline(streams=3, min_chunk=int(rng.choice([7, 64, 4096])), max_chunks=12)
     eng.set_templates_dense(tm, tf, valid)
     d_pcm = torch.from_numpy(pcm.view(np.int16)).to("cuda:0")
     out = eng.recognize_dev(d_pcm, eng.alloc_outputs(B, "cuda:0"))
@@ -727,14 +724,14 @@ def _multi_case(devices, golden):
 def test_multi_gpu_bookkeeping_with_in_process_collective_double(n):
     """The N > 1 index arithmetic of csrc/sr_multi.cpp (block offsets of the in-place all-gather, padded last shard,
     EMPTY last shard when B < n, read-back from the owning devices / device 0) executed on this 1-GPU box: n ranks on
-    device 0 (SR_MULTI_TEST_ALLOW_DUP=1) over tests/fake_rccl/librccl.so.1 (SR_RCCL_LIBRARY), an in-process stand-in
+    device 0 (development hook "multi_allow_dup") over tests/fake_rccl/librccl.so.1 (SR_RCCL_LIBRARY), an in-process stand-in
     that performs the all-gather as stream-ordered device copies between the ranks' buffers.  Own process: the
     collective library is bound once per process, and the other tests of this module use the real RCCL."""
     import json
     import subprocess
     import multi_case as mc
     assert os.path.exists(mc.FAKE_RCCL), "tests/fake_rccl/librccl.so.1 missing: run __graft_entry__.build()"
-    env = dict(os.environ, SR_RCCL_LIBRARY=mc.FAKE_RCCL, SR_MULTI_TEST_ALLOW_DUP="1")
+    env = dict(os.environ, SR_RCCL_LIBRARY=mc.FAKE_RCCL)  # multi_case.py switches the duplicate-device hook on itself
     Bs = [37, 24, n - 1, 1]                 # uneven shards; even shards; B < n (empty last shard); a single capture
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "multi_case.py"), ",".join(["0"] * n),
                         ",".join(map(str, Bs))], env=env, capture_output=True, text=True, timeout=600)
@@ -761,7 +758,7 @@ def _run_bench(extra, env_extra, timeout=900):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
                                                               "SR_BENCH_BACKEND", "SR_BENCH_DEVICE", "SR_RCCL_LIBRARY",
-                                                              "SR_MULTI_TEST_ALLOW_DUP", "SR_BENCH_FORCE_DIST")}
+                                                              "SR_BENCH_FORCE_DIST")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True, text=True,
                        timeout=timeout, cwd=root)
@@ -781,6 +778,13 @@ def test_bench_plain_command_launches_its_own_ranks():
     assert j["config"]["batch_per_gpu"] == 4096 and "all-gather" in j["config"]["parallelism"]
     assert abs(j["value"] - 2 * 4096 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
     assert j["top1_word_accuracy"] == 1.0
+    x = j["exchange"]
+    assert x["ranks_in_communicator"] == 2 and len(x["step_ms_per_rank"]) == 2 and x["allgather_bytes_per_rank_out"] == 2 * 4096 * 100 * 4
+    # strong scaling: the global batch is fixed and split over the ranks
+    j, _ = _run_bench(["--gpus", "2", "--scaling", "strong", "--batch", "8192", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                      dict(SR_BENCH_BACKEND="gloo", SR_BENCH_DEVICE="0"))
+    assert j["scaling"] == "strong" and j["config"]["batch_per_gpu"] == 4096 and "global batch 8192" in j["config"]["workload"]
+    assert abs(j["value"] - 8192 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
 
 
 def test_bench_rccl_calls_with_one_rank():
@@ -791,6 +795,9 @@ def test_bench_rccl_calls_with_one_rank():
     j, _ = _run_bench(["--batch", "4096", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"],
                       dict(SR_BENCH_FORCE_DIST="1"))
     assert j["n_gpus"] == 1 and "TEST HOOK" in j["config"]["parallelism"] and j["top1_word_accuracy"] == 1.0
+    x = j["exchange"]  # diagnostics of the exchange step: communicator size as RCCL reports it, the collective timed alone
+    assert x["backend"] == "nccl" and x["ranks_in_communicator"] == 1 and len(x["step_ms_per_rank"]) == 1
+    assert x["allgather_ms"] > 0 and x["exposed_allgather_ms"] >= 0 and x["allgather_bytes_per_rank_out"] == 4096 * 100 * 4
 
 
 def test_bench_plain_command_single_process_launcher():
@@ -799,7 +806,7 @@ def test_bench_plain_command_single_process_launcher():
     collective library is the in-process double (tests/fake_rccl); with two devices the next test uses RCCL."""
     import multi_case as mc
     j, _ = _run_bench(["--gpus", "2", "--launcher", "single", "--batch", "4096", "--steps", "2", "--warmup", "1"],
-                      dict(SR_BENCH_DEVICE="0", SR_RCCL_LIBRARY=mc.FAKE_RCCL, SR_MULTI_TEST_ALLOW_DUP="1"))
+                      dict(SR_BENCH_DEVICE="0", SR_RCCL_LIBRARY=mc.FAKE_RCCL))
     assert j["n_gpus"] == 2 and j["launcher"].startswith("single") and "TEST HOOK" in j["config"]["parallelism"]
     assert abs(j["value"] - 2 * 4096 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
     assert j["top1_word_accuracy"] == 1.0 and j["roofline"]["frac"] > 0

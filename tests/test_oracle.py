@@ -127,18 +127,20 @@ def test_log_step_table_is_checked_against_the_shipped_positions():
     log differs in the last bit at one of the 2219 integer crossings would silently shift a step relative to the golden
     fixtures: the library ships the positions of the libm the fixtures were made with (csrc/sr_log_thr_ref.inc), compares,
     reports (sr_log_table_mismatches, warning in sr_last_error and on stderr) and uses the shipped ones.  Here: this host
-    agrees; a perturbed host table (test hook) is detected and replaced; SR_LOG_THR_FROM_HOST keeps the host's."""
+    agrees; a perturbed host table (development hook) is detected and replaced; "log_thr_from_host" keeps the host's."""
     import subprocess
     import sys
-    code = ("import ctypes as C\n"
-            "from stm32_speech_recognition_amd.engine import build_tables, load_library\n"
+    code = ("import ctypes as C, os\n"
+            "from stm32_speech_recognition_amd.engine import build_tables, load_library, dev_hook\n"
+            "dev_hook('perturb_log_thr', int(os.environ.get('T_PERTURB', '0')))\n"
+            "dev_hook('log_thr_from_host', int(os.environ.get('T_FROM_HOST', '0')))\n"
             "t = build_tables()['log_thr']\n"
             "L = load_library(); L.sr_last_error.restype = C.c_char_p\n"
             "print(L.sr_log_table_mismatches(), int(t[1000]), int(t[1001]), L.sr_last_error().decode()[:40])\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(**env):
-        e = {k: v for k, v in os.environ.items() if k not in ("SR_TEST_PERTURB_LOG_THR", "SR_LOG_THR_FROM_HOST")}
+        e = {k: v for k, v in os.environ.items() if k not in ("T_PERTURB", "T_FROM_HOST")}
         p = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), capture_output=True, text=True, cwd=root, timeout=120)
         assert p.returncode == 0, p.stderr
         f = p.stdout.split(None, 3)
@@ -146,9 +148,9 @@ def test_log_step_table_is_checked_against_the_shipped_positions():
 
     bad, t1000, t1001, msg, err = run()
     assert bad == 0 and "warning" not in msg and "warning" not in err       # the test host's libm agrees with the shipped table
-    bad, p1000, p1001, msg, err = run(SR_TEST_PERTURB_LOG_THR="1000")
+    bad, p1000, p1001, msg, err = run(T_PERTURB="1000")
     assert bad == 1 and (p1000, p1001) == (t1000, t1001) and msg.startswith("warning") and "libm" in err
-    bad, h1000, _, _, _ = run(SR_TEST_PERTURB_LOG_THR="1000", SR_LOG_THR_FROM_HOST="1")
+    bad, h1000, _, _, _ = run(T_PERTURB="1000", T_FROM_HOST="1")
     assert bad == 1 and h1000 == t1000 + 1
 
 

@@ -36,6 +36,8 @@ def _worker(rank, world, port, B_total, K, q):
     local = torch.from_numpy(_fake_scores(lo, hi, K).view(np.int32))
     gathered = du.all_gather_scores(local, world)
     t = du.max_over_ranks(1.0 + rank, "cpu", world)
+    per_rank = du.gather_floats(10.0 + rank, "cpu", world)  # bench.py's per-rank step times
+    assert per_rank == [10.0 + r for r in range(world)]
     best, mn = du.argmin_first(gathered)
     q.put((rank, lo, hi, gathered.numpy().view(np.uint32).copy(), t, best.numpy(), mn.numpy()))
     torch.distributed.barrier()
