@@ -155,6 +155,12 @@ int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
 int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                            sr_result *d_results, uint32_t *d_scores, int16_t *d_mfcc, sr_vad_rec *d_vad,
                            void *stream);
+/* sr_recognize_batch for HOST callers whose captures are 12-bit ADC codes (ADC.H:7-11: the firmware's converter), packed
+ * two samples in three bytes: sample 2i = b[3i] | (b[3i+1] & 0x0F) << 8, sample 2i+1 = b[3i+1] >> 4 | b[3i+2] << 4; row b
+ * starts at packed + b*row_stride_bytes and holds ceil(buf_len / 2) * 3 bytes.  The host-buffer path is PCIe-bound
+ * (INTEGRATION.md 2); this moves 25 % fewer bytes and unpacks on the device.  Same results as the u16 call on the same codes. */
+int sr_recognize_batch_packed12(sr_engine *h, const uint8_t *packed, uint64_t row_stride_bytes, uint32_t buf_len, uint32_t B,
+                                sr_result *results, uint32_t *scores, int16_t *mfcc, sr_vad_rec *vad);
 
 /* Multi-segment recognition: every segment the VAD returns (up to max_seg, VAD.H:4) is matched like segment 0.
  * The firmware stops at segment 0 (main.c:268); this is an extension with segment-major outputs:

@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stm32_speech_recognition_amd import Engine, synth  # noqa: E402
-from stm32_speech_recognition_amd.engine import vad_from_torch  # noqa: E402
+from stm32_speech_recognition_amd.engine import pack12, vad_from_torch  # noqa: E402
 
 
 def main():
@@ -43,6 +43,18 @@ def main():
         assert np.array_equal(res, res0)
         t = min(ts)
         out[name] = {"ms": round(t * 1e3, 2), "utt_per_s": round(B / t), "upload_GBps": round(B * S * 2 / t / 1e9, 1)}
+    # 12-bit codes packed two samples in three bytes (sr_recognize_batch_packed12): 25 % fewer bytes over PCIe
+    pk = pack12(d_pcm.cpu().numpy().view(np.uint16))
+    for name, host in (("packed12_pageable", pk), ("packed12_pinned", torch.from_numpy(pk).pin_memory().numpy())):
+        eng.recognize_packed12(host, S, want_scores=False, want_mfcc=False, want_vad=False)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            resp = eng.recognize_packed12(host, S, want_scores=False, want_mfcc=False, want_vad=False)["results"]
+            ts.append(time.perf_counter() - t0)
+        assert np.array_equal(resp, res0)
+        t = min(ts)
+        out[name] = {"ms": round(t * 1e3, 2), "utt_per_s": round(B / t), "upload_GBps": round(pk.nbytes / t / 1e9, 1)}
     o = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
     eng.recognize_dev(d_pcm, o)
     torch.cuda.synchronize()

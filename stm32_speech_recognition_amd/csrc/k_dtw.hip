@@ -145,6 +145,61 @@ __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
     a.scores[pid] = d;
 }
 
+// ---- k_dtw_gen: the same walk for feature rows of any width (GENERIC front end, n_coef != 12) -----------------------
+// One lane per pair, rows read coefficient by coefficient from global memory (rows of an odd number of s16 are only
+// 2-byte aligned), get_dis as written in DTW.C:45-62.  Slow and simple: stores with 12 coefficients never come here.
+__device__ __forceinline__ uint32_t get_dis_n(const int16_t *pa, const int16_t *pb, uint32_t nc)
+{
+    uint32_t d = 0;
+    for (uint32_t i = 0; i < nc; i++) {
+        const int v = (int)pa[i] - (int)pb[i];
+        d += (uint32_t)(v * v);
+    }
+    return cvt_u32(sqrt_rn_int((float)d));
+}
+__global__ void __launch_bounds__(128) k_dtw_gen(const DtwArgs a)
+{
+    const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= (uint64_t)a.B * a.K) return;
+    const uint32_t b = (uint32_t)(pid / a.K), k = (uint32_t)(pid - (uint64_t)b * a.K), nc = a.n_coef;
+    uint32_t in_n, ok;
+    if (a.in_frames) {
+        in_n = a.in_frames[b];
+        ok = in_n != 0;
+    } else {
+        in_n = a.vad[b].frm_num;
+        ok = a.vad[b].status == SR_ST_OK && in_n != 0;
+    }
+    uint32_t score = SR_DIS_ERR;
+    const uint32_t mdl_n = a.tpl_frames[k];
+    if (ok && a.tpl_valid[k] && !(in_n > mdl_n * 2 || 2 * in_n < mdl_n)) {  // main.c:283, DTW.C:133-137
+        const int16_t *in = a.mfcc + (size_t)b * a.max_frames * nc, *mdl = a.tpl + (size_t)k * a.tpl_stride;
+        const uint32_t in_rows = a.max_frames, mdl_rows = a.tpl_rows;
+        const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142
+        const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
+        uint32_t px = 0, py = 0, dis = get_dis_n(in, mdl, nc), step = 1;
+        do {
+            // rows px+1 / py+1 are read even past the sequence end (do-while, DTW.C:150-154), clamped to the allocation
+            const uint32_t rx = (px + 1 < in_rows) ? px + 1 : in_rows - 1, ry = (py + 1 < mdl_rows) ? py + 1 : mdl_rows - 1;
+            const int16_t *ci = in + (size_t)px * nc, *ni = in + (size_t)rx * nc, *cm = mdl + (size_t)py * nc, *nm = mdl + (size_t)ry * nc;
+            const int x = (int)px + 1, y = (int)py + 1;
+            const uint32_t up = dtw_out(x, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(nm, ci, nc);
+            const uint32_t right = dtw_out(x + 1, y, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(cm, ni, nc);
+            const uint32_t diag = dtw_out(x + 1, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(nm, ni, nc);
+            uint32_t mn = diag;  // DTW.C:156-164
+            if (mn > right) mn = right;
+            if (mn > up) mn = up;
+            dis += mn;
+            const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
+            if (mv_diag || !mv_up) px++;
+            if (mv_diag || mv_up) py++;
+            step = (step + 1) & 0xFFFF;
+        } while (px + 1 < in_n && py + 1 < mdl_n);  // DTW.C:188
+        score = dis / step;
+    }
+    a.scores[pid] = score;
+}
+
 // ---- k_dtw_lds: the production DTW kernel ---------------------------------------------------------
 // A workgroup owns U utterances whose MFCC rows (+ squared norms) are staged in LDS once and reused by
 // all K templates; lanes are the U*K pairs ordered (template-sorted-by-length major, utterance minor),
@@ -528,6 +583,10 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
     const uint64_t n = (uint64_t)a.B * a.K;
     if (!n) return;
     // U (utterances per workgroup) and the LDS size were chosen once, when the template store was set
+    if (a.n_coef != kCoef) {  // GENERIC front end with another feature width
+        hipLaunchKernelGGL(k_dtw_gen, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
+        return;
+    }
     const uint32_t U = a.tplR ? a.lds_u : 0;
     const size_t lds = a.lds_bytes;
     if (U) {

@@ -245,6 +245,10 @@ uint32_t mfcc_resident_workgroups(uint32_t frame_len)
 
 void launch_mfcc(const MfccArgs &a, hipStream_t s)
 {
+    if (a.generic) {
+        launch_mfcc_gen(a, s);
+        return;
+    }
     if (a.n_items == 0) return;
     // persistent-style grid: a few times the workgroups that are resident at once (see sr_create), work items strided
     const uint32_t cap = a.grid_cap ? a.grid_cap : 4096u;

@@ -12,12 +12,12 @@ namespace sr {
 // are zero.  Defined in oracle/sr_oracle.c (sr_oracle_delta_mfcc); pure streaming: one thread per output element.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames,
-                                                    uint32_t B, uint32_t max_frames, int16_t *delta)
+                                                    uint32_t B, uint32_t max_frames, uint32_t nc, int16_t *delta)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t per = max_frames * kCoef;
+    const uint32_t per = max_frames * nc;
     if (i >= (uint64_t)B * per) return;
-    const uint32_t b = (uint32_t)(i / per), r = (uint32_t)(i - (uint64_t)b * per), t = r / kCoef, c = r - t * kCoef;
+    const uint32_t b = (uint32_t)(i / per), r = (uint32_t)(i - (uint64_t)b * per), t = r / nc, c = r - t * nc;
     uint32_t n = frames ? frames[b] : ((vad[b].status == SR_ST_OK) ? vad[b].frm_num : 0u);
     if (n > max_frames) n = max_frames;
     int16_t out = 0;
@@ -25,17 +25,45 @@ __global__ void __launch_bounds__(256) k_delta_mfcc(const int16_t *mfcc, const s
         const int16_t *m = mfcc + (uint64_t)b * per + c;
         const uint32_t p1 = t + 1 < n ? t + 1 : n - 1, p2 = t + 2 < n ? t + 2 : n - 1;
         const uint32_t m1 = t >= 1 ? t - 1 : 0, m2 = t >= 2 ? t - 2 : 0;
-        const int num = ((int)m[p1 * kCoef] - (int)m[m1 * kCoef]) + 2 * ((int)m[p2 * kCoef] - (int)m[m2 * kCoef]);
+        const int num = ((int)m[p1 * nc] - (int)m[m1 * nc]) + 2 * ((int)m[p2 * nc] - (int)m[m2 * nc]);
         out = (int16_t)(num / 10);
     }
     delta[i] = out;
 }
 void launch_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames, uint32_t B, uint32_t max_frames,
-                       int16_t *delta, hipStream_t s)
+                       uint32_t n_coef, int16_t *delta, hipStream_t s)
 {
-    const uint64_t n = (uint64_t)B * max_frames * kCoef;
+    const uint64_t n = (uint64_t)B * max_frames * n_coef;
     if (!n) return;
-    hipLaunchKernelGGL(k_delta_mfcc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, mfcc, vad, frames, B, max_frames, delta);
+    hipLaunchKernelGGL(k_delta_mfcc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, mfcc, vad, frames, B, max_frames, n_coef, delta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_unpack12: host transport of 12-bit ADC codes (ADC.H:7-11: the STM32's 12-bit converter) packed two samples in three
+// bytes -- sample 2i = b[3i] | (b[3i+1] & 0x0F) << 8, sample 2i+1 = b[3i+1] >> 4 | b[3i+2] << 4 -- back into the u16
+// capture rows every kernel of the path reads.  One thread per 8 samples: 12 bytes in (three aligned dwords), 16 bytes out.
+// A streaming kernel (HBM-bound: 1.5 + 2 bytes per sample); it exists so that the PCIe upload moves 25 % fewer bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_unpack12(const uint32_t *packed, uint64_t row_words, uint16_t *out, uint64_t out_stride,
+                                                  uint32_t groups_per_row, uint32_t B)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)B * groups_per_row) return;
+    const uint32_t b = (uint32_t)(i / groups_per_row), g = (uint32_t)(i - (uint64_t)b * groups_per_row);
+    const uint32_t *src = packed + (uint64_t)b * row_words + 3ull * g;
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];  // 24 nibbles, 8 samples of 3 nibbles each, little-endian
+    const uint32_t s0 = w0 & 0xFFFu, s1 = (w0 >> 12) & 0xFFFu, s2 = (w0 >> 24) | ((w1 & 0xFu) << 8), s3 = (w1 >> 4) & 0xFFFu;
+    const uint32_t s4 = (w1 >> 16) & 0xFFFu, s5 = (w1 >> 28) | ((w2 & 0xFFu) << 4), s6 = (w2 >> 8) & 0xFFFu, s7 = w2 >> 20;
+    *(uint4 *)(out + (uint64_t)b * out_stride + 8ull * g) = make_uint4(s0 | s1 << 16, s2 | s3 << 16, s4 | s5 << 16, s6 | s7 << 16);
+}
+void launch_unpack12(const void *packed, uint64_t row_bytes, uint16_t *out, uint64_t out_stride, uint32_t buf_len, uint32_t B,
+                     hipStream_t s)
+{
+    const uint32_t groups = (buf_len + 7) / 8;
+    const uint64_t n = (uint64_t)B * groups;
+    if (!n) return;
+    hipLaunchKernelGGL(k_unpack12, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t *)packed, row_bytes / 4, out,
+                       out_stride, groups, B);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -54,7 +54,9 @@ struct VadArgs {
     sr_vad_rec *vad;      // [B]
     const sr_atap *atap_in;  // optional [B]: use these thresholds instead of running noise_atap
     uint64_t *dbg_masks;     // optional [B][16]: per-round ballot of "loud" frames (diagnostics)
-    uint32_t frame_len;      // 160 (reference) or 320 (extension)
+    uint32_t frame_len;      // 160 (reference), 320 (extension) or one of the generic front end's framings (k_vad_gen.hip)
+    uint32_t v_durmin;       // VAD.C:72-73: 80 ms / (frame_time - frame_mov_t) frames (8 at 20 / 10 ms)
+    uint32_t s_durmax;       // VAD.C:74-75: 110 ms / (frame_time - frame_mov_t) frames (11)
 };
 
 struct MfccArgs {
@@ -68,6 +70,8 @@ struct MfccArgs {
     uint32_t n_items;       // B * tiles
     uint32_t grid_cap;      // resident workgroups of k_mfcc on this device (0 = default)
     uint32_t frame_len;     // 160 -> k_mfcc (reference front end), 320 -> k_mfcc_ext (extension)
+    uint32_t generic;       // 1 -> k_mfcc_gen (GENERIC front end): the four fields below are only read there
+    uint32_t hop, n_mel, n_coef;
     DevTables t;
 };
 
@@ -94,6 +98,7 @@ struct DtwArgs {
     const int8_t *tie_delta;      // DevTables::tie_delta
     uint32_t tie_g;               // entries of it the workgroup stages in LDS (a multiple of 1024, <= kTieMax)
     uint32_t lds_kc;              // templates per k_dtw_lds workgroup (dtw_lds_pick_u); the store is walked in K / lds_kc chunks
+    uint32_t n_coef;              // s16 per feature row: 12 everywhere except the GENERIC front end (-> k_dtw_gen when != 12)
     uint32_t dp_lanes;            // k_dtw_dp only: lanes per pair of the band kernel (4 / 8 / 16; 0 = default 8; 1 = k_dtw_dp_wave64)
 };
 
@@ -114,9 +119,11 @@ struct GetMdlArgs {
 void launch_get_mdl(const GetMdlArgs &a, hipStream_t s);
 
 void launch_vad(const VadArgs &a, hipStream_t s);
+bool vad_framing_supported(uint32_t frame_len, uint32_t hop);  // the VAD kernel is instantiated per framing
 void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
                            uint32_t frame_len, uint32_t hop, hipStream_t s);
 void launch_mfcc(const MfccArgs &a, hipStream_t s);
+void launch_mfcc_gen(const MfccArgs &a, hipStream_t s);  // GENERIC front end (k_mfcc_gen.hip)
 uint32_t mfcc_frames_per_tile(uint32_t frame_len);      // frames one work item of the frame kernel covers
 uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on the current device
 void launch_dtw(const DtwArgs &a, hipStream_t s);
@@ -133,7 +140,10 @@ void launch_fft_mag(const int16_t *frames, uint32_t len, uint32_t *mag, uint32_t
                     const DevTables &t, hipStream_t s);
 // EXTENSION: delta cepstra of B records (frame counts from vad[] or, when non-null, frames[])
 void launch_delta_mfcc(const int16_t *mfcc, const sr_vad_rec *vad, const uint32_t *frames, uint32_t B, uint32_t max_frames,
-                       int16_t *delta, hipStream_t s);
+                       uint32_t n_coef, int16_t *delta, hipStream_t s);
+// host transport: rows of 12-bit codes packed 2 samples / 3 bytes (row_bytes a multiple of 12) -> u16 rows (out_stride samples)
+void launch_unpack12(const void *packed, uint64_t row_bytes, uint16_t *out, uint64_t out_stride, uint32_t buf_len, uint32_t B,
+                     hipStream_t s);
 // diagnostics: log / sqrt device functions swept directly (see k_math_diag)
 void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
 // get_dis (DTW.C:45-62) for n frame pairs

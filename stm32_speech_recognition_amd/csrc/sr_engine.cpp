@@ -93,7 +93,10 @@ struct sr_engine {
     int device = 0;
     uint32_t noise_len = 0, atap_frm = 0;
     uint32_t mfcc_tile = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item, resident workgroups
-    uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension
+    uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension, or the generic front end's framing
+    uint32_t nc = 12, n_mel = 24;                // s16 per feature row (n_coef), Mel filters
+    bool generic = false;                        // GENERIC front end (k_mfcc_gen / k_dtw_gen when nc != 12)
+    uint32_t v_durmin = 8, s_durmax = 11;        // VAD.C:72-75 in frames
     HostTables host;
     DevTables dev{};
     void *table_blob = nullptr;
@@ -109,6 +112,7 @@ struct sr_engine {
     uint32_t dp_lanes = 0;         // sr_set_dp_lanes: lanes per pair of the opt-in full-DP scorer (0 = default)
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
+    DevBuf<uint8_t> s_pack;   // sr_recognize_batch_packed12: the packed rows as uploaded, before k_unpack12
     DevBuf<sr_vad_rec> s_vad;
     DevBuf<int16_t> s_mfcc;
     DevBuf<uint32_t> s_scores;
@@ -175,16 +179,29 @@ void sr_default_config(sr_config *c)
     c->device = -1;
 }
 
-// Two front ends are built: the reference's (8 kHz, 160/80 framing, 1024-point FFT, 24 Mel) and the
-// 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
+// Two front ends have specialised kernels: the reference's (8 kHz, 160/80 framing, 1024-point FFT, 24 Mel, 12 MFCC) and the
+// 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).  Every other accepted
+// configuration runs the GENERIC front end (k_mfcc_gen + the VAD instance of its framing; round 4): the reference's
+// compile-time constants (MFCC.H:7-16, VAD.H:4-8, ADC.H:7-11) as run-time values -- any fs that is a multiple of 1000 Hz,
+// 1024-point transform, frame_time = 2 * frame_mov with a framing the VAD kernel is instantiated for (frame_len 160, 240,
+// 256, 320, 400, 512 samples), an even number of 4..64 Mel filters, 1..16 coefficients.
 static int front_end_of(const sr_config *cfg, FrontEnd *fe)
 {
     const bool is_ref = cfg->fs == 8000 && cfg->nfft == 1024 && cfg->n_mel == 24;
     const bool is_ext = cfg->fs == 16000 && cfg->nfft == 512 && cfg->n_mel == 40;
-    if (!(is_ref || is_ext) || cfg->frame_time_ms != 20 || cfg->frame_mov_ms != 10 || cfg->n_coef != 12)
-        return fail(SR_ERR_BAD_CONFIG,
-                    "supported: fs=8000/nfft=1024/24 Mel (reference) or fs=16000/nfft=512/40 Mel (extension), 20/10 ms, 12 MFCC");
-    *fe = is_ext ? kFrontExt : kFrontRef;
+    if ((is_ref || is_ext) && cfg->frame_time_ms == 20 && cfg->frame_mov_ms == 10 && cfg->n_coef == 12) {
+        *fe = is_ext ? kFrontExt : kFrontRef;
+        return SR_OK;
+    }
+    const char *what = "supported: fs=8000/nfft=1024/24 Mel/12 MFCC (reference), fs=16000/nfft=512/40 Mel/12 MFCC (extension), or the generic "
+                       "front end: nfft=1024, fs a multiple of 1000, frame_time_ms = 2*frame_mov_ms with frame_len in {160,240,256,320,400,512}, "
+                       "n_mel even 4..64, n_coef 1..16";
+    if (cfg->nfft != 1024 || cfg->fs == 0 || cfg->fs % 1000 || cfg->fs > 1000000) return fail(SR_ERR_BAD_CONFIG, what);
+    const uint32_t fl = cfg->fs / 1000 * cfg->frame_time_ms, mov = cfg->fs / 1000 * cfg->frame_mov_ms;
+    if (cfg->frame_time_ms != 2 * cfg->frame_mov_ms || fl < 2 || fl > 1024 || !vad_framing_supported(fl, fl - mov))
+        return fail(SR_ERR_BAD_CONFIG, what);
+    if ((cfg->n_mel & 1) || cfg->n_mel < 4 || cfg->n_mel > 64 || cfg->n_coef < 1 || cfg->n_coef > 16) return fail(SR_ERR_BAD_CONFIG, what);
+    *fe = FrontEnd{(int)cfg->fs, (int)fl, (int)(fl - mov), 1024, 512, (int)cfg->n_mel, (int)cfg->n_coef, true};
     return SR_OK;
 }
 
@@ -284,13 +301,22 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->atap_frm = atap_frm;
     h->frame_len = (uint32_t)fe.frame_len;
     h->hop = (uint32_t)fe.hop;
-    h->mfcc_tile = mfcc_frames_per_tile(h->frame_len);
+    h->nc = (uint32_t)fe.n_coef;
+    h->n_mel = (uint32_t)fe.n_mel;
+    h->generic = fe.generic;
+    h->v_durmin = 80 / (cfg->frame_time_ms - cfg->frame_mov_ms);   // VAD.C:72-75
+    h->s_durmax = 110 / (cfg->frame_time_ms - cfg->frame_mov_ms);
+    if (h->v_durmin < 1 || h->s_durmax < 1) {
+        delete h;
+        return fail(SR_ERR_BAD_CONFIG, "frame_time_ms - frame_mov_ms must not exceed 80 ms (VAD.C:72-75)");
+    }
+    h->mfcc_tile = h->generic ? 1u : mfcc_frames_per_tile(h->frame_len);
     // Grid of the frame kernel: FOUR times the workgroups that are resident at once, work items strided.  Exactly the
     // resident set (one persistent wave of workgroups) left ~15 % of the kernel's own time to stragglers: the workgroups
     // do not finish together, and with more, shorter ones the dispatcher back-fills the CUs that are done (measured alone
     // on the chip, 65 536 x 256 frames: 1024 workgroups 19.0 ms, 2048 17.8, 4096 17.1, 16 384 16.6; the per-workgroup
     // set-up -- coefficient and DCT tables -- is amortised over 80 items at 4096).
-    h->mfcc_grid_cap = 4 * mfcc_resident_workgroups(h->frame_len);
+    h->mfcc_grid_cap = h->generic ? 0u : 4 * mfcc_resident_workgroups(h->frame_len);
     if (const int64_t gv = dev_hook(kHookMfccGrid)) {  // development hook: workgroups of the frame kernel
         if (gv > 0) h->mfcc_grid_cap = (uint32_t)gv;
     }
@@ -362,6 +388,7 @@ void sr_destroy(sr_engine *h)
     h->tpl_frames_s.release();
     h->tpl_orig.release();
     h->s_pcm.release();
+    h->s_pack.release();
     h->s_vad.release();
     h->s_mfcc.release();
     h->s_scores.release();
@@ -394,6 +421,7 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
                             const std::vector<uint8_t> &v, uint32_t K, uint32_t rows)
 {
     ENTER_DEVICE(h);
+    const uint32_t nc = h->nc;  // s16 per feature row; the staged kernels (k_dtw_lds, k_dtw_dp_band) are built for 12
     HIP_TRY(hipDeviceSynchronize());
     DevBuf<int16_t> n_tpl;
     DevBuf<uint32_t> n_frames, n_tplR, n_frames_s, n_orig;
@@ -419,10 +447,11 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
         // (unreachable for log-Mel cepstra, reachable for arbitrary s16 records) disable the staged kernel for
         // this store and the generic k_dtw, which makes no such assumption, scores it.
         std::vector<uint32_t> rt((size_t)rows * K * 8, 0u), fs(K);
+        if (nc != (uint32_t)kCoef) fits = false;  // another feature width: the generic kernel scores the store
         for (uint32_t ks = 0; ks < K; ks++) {
             const uint32_t k = order[ks];
             fs[ks] = v[k] ? f[k] : 0u;
-            for (uint32_t r = 0; r < rows; r++) {
+            for (uint32_t r = 0; r < rows && nc == (uint32_t)kCoef; r++) {
                 const int16_t *src = &m[((size_t)k * rows + r) * kCoef];
                 uint32_t *dst = &rt[((size_t)r * K + ks) * 8];
                 int16_t neg2[kCoef];
@@ -481,7 +510,7 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     }
     h->K = K;
     h->tpl_rows = rows;
-    h->tpl_stride = rows * kCoef;
+    h->tpl_stride = rows * nc;
     return SR_OK;
 }
 
@@ -489,8 +518,9 @@ int sr_set_templates_dense(sr_engine *h, const int16_t *mfcc, const uint32_t *fr
                            uint32_t K, uint32_t tpl_stride)
 {
     if (!h || !mfcc || !frames || K == 0) return fail(SR_ERR_BAD_ARG, "null/empty template set");
-    if (tpl_stride % kCoef) return fail(SR_ERR_BAD_ARG, "tpl_stride must be a multiple of n_coef");
-    const uint32_t src_rows = tpl_stride / kCoef;
+    const uint32_t nc = h->nc;
+    if (tpl_stride % nc) return fail(SR_ERR_BAD_ARG, "tpl_stride must be a multiple of n_coef");
+    const uint32_t src_rows = tpl_stride / nc;
     uint32_t maxf = 1;
     for (uint32_t k = 0; k < K; k++) {
         if (frames[k] > src_rows) return fail(SR_ERR_BAD_ARG, "template frame count exceeds its stride");
@@ -499,12 +529,12 @@ int sr_set_templates_dense(sr_engine *h, const int16_t *mfcc, const uint32_t *fr
     }
     // one row of slack: the do-while of DTW.C:150-154 reads row 1 of a 1-frame template
     const uint32_t rows = maxf + 1;
-    std::vector<int16_t> m((size_t)K * rows * kCoef, 0);
+    std::vector<int16_t> m((size_t)K * rows * nc, 0);
     std::vector<uint32_t> f(frames, frames + K);
     std::vector<uint8_t> v(K, 1);
     for (uint32_t k = 0; k < K; k++) {
         const uint32_t copy_rows = src_rows < rows ? src_rows : rows;
-        std::memcpy(&m[(size_t)k * rows * kCoef], mfcc + (size_t)k * tpl_stride, (size_t)copy_rows * kCoef * 2);
+        std::memcpy(&m[(size_t)k * rows * nc], mfcc + (size_t)k * tpl_stride, (size_t)copy_rows * nc * 2);
         if (valid) v[k] = valid[k] ? 1 : 0;
     }
     return upload_templates(h, m, f, v, K, rows);
@@ -513,10 +543,11 @@ int sr_set_templates_dense(sr_engine *h, const int16_t *mfcc, const uint32_t *fr
 int sr_set_templates(sr_engine *h, const void *store, uint32_t n_slots, uint32_t stride_bytes)
 {
     if (!h || !store || n_slots == 0) return fail(SR_ERR_BAD_ARG, "null/empty template store");
-    if (stride_bytes < 4 + 2 * kCoef) return fail(SR_ERR_BAD_ARG, "slot stride too small for a v_ftr_tag");
+    const uint32_t nc = h->nc;
+    if (stride_bytes < 4 + 2 * nc) return fail(SR_ERR_BAD_ARG, "slot stride too small for a v_ftr_tag");
     // v_ftr_tag image: u16 save_sign | u16 frm_num | s16 mfcc_dat[] (MFCC.H:18-25), slot stride Flash.H:13
     const uint8_t *s = (const uint8_t *)store;
-    const uint32_t slot_rows = (stride_bytes - 4) / (2 * kCoef);
+    const uint32_t slot_rows = (stride_bytes - 4) / (2 * nc);
     std::vector<uint32_t> f(n_slots);
     std::vector<uint8_t> v(n_slots);
     uint32_t maxf = 1;
@@ -533,11 +564,11 @@ int sr_set_templates(sr_engine *h, const void *store, uint32_t n_slots, uint32_t
         }
     }
     uint32_t rows = maxf + 1;
-    std::vector<int16_t> m((size_t)n_slots * rows * kCoef, 0);
+    std::vector<int16_t> m((size_t)n_slots * rows * nc, 0);
     for (uint32_t k = 0; k < n_slots; k++) {
         if (!v[k]) continue;
         const uint32_t copy_rows = slot_rows < rows ? slot_rows : rows;  // keeps whatever follows frm_num rows
-        std::memcpy(&m[(size_t)k * rows * kCoef], s + (size_t)k * stride_bytes + 4, (size_t)copy_rows * kCoef * 2);
+        std::memcpy(&m[(size_t)k * rows * nc], s + (size_t)k * stride_bytes + 4, (size_t)copy_rows * nc * 2);
     }
     return upload_templates(h, m, f, v, n_slots, rows);
 }
@@ -626,6 +657,13 @@ static int check_pcm(const sr_engine *h, const uint16_t *pcm, uint64_t stride, u
     return SR_OK;
 }
 
+static VadArgs vad_args(const sr_engine *h, const uint16_t *pcm, uint64_t stride, uint32_t buf_len, uint32_t noise_len, uint32_t B,
+                        sr_vad_rec *vad, const sr_atap *atap_in = nullptr, uint64_t *dbg = nullptr)
+{
+    return VadArgs{pcm, stride, buf_len, noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, vad, atap_in, dbg,
+                   h->frame_len, h->v_durmin, h->s_durmax};
+}
+
 int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                      sr_vad_rec *d_vad, void *stream)
 {
@@ -633,7 +671,7 @@ int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, u
     int rc = check_pcm(h, d_pcm, pcm_stride, buf_len);
     if (rc) return rc;
     ENTER_DEVICE(h);
-    VadArgs a{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr, h->frame_len};
+    VadArgs a = vad_args(h, d_pcm, pcm_stride, buf_len, h->noise_len, B, d_vad);
     launch_vad(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SR_OK;
@@ -653,6 +691,10 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.grid_cap = h->mfcc_grid_cap;
     a.frame_len = h->frame_len;
     a.n_items = B * a.tiles;
+    a.generic = h->generic ? 1u : 0u;
+    a.hop = h->hop;
+    a.n_mel = h->n_mel;
+    a.n_coef = h->nc;
     a.t = h->dev;
     return a;
 }
@@ -694,6 +736,7 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.tie_delta = h->dev.tie_delta;
     a.tie_g = h->dtw_tie_g;
     a.lds_kc = h->dtw_kc;
+    a.n_coef = h->nc;
     a.dp_lanes = h->dp_lanes;
     return a;
 }
@@ -727,7 +770,7 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
         d_vad = h->s_vad.p;
     }
     if (!d_mfcc) {
-        if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+        if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * h->nc))) return rc;
         d_mfcc = h->s_mfcc.p;
     }
     if (!d_scores) {
@@ -769,8 +812,8 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
         hipEvent_t *ev = prof ? &h->ev[5 * (h->ev_used + c)] : nullptr;
         const uint16_t *pc = d_pcm + (size_t)b0 * pcm_stride;
         sr_vad_rec *vc = d_vad + b0;
-        int16_t *mc = d_mfcc + (size_t)b0 * h->cfg.max_frames * kCoef;
-        VadArgs va{pc, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, n, vc, nullptr, nullptr, h->frame_len};
+        int16_t *mc = d_mfcc + (size_t)b0 * h->cfg.max_frames * h->nc;
+        VadArgs va = vad_args(h, pc, pcm_stride, buf_len, h->noise_len, n, vc);
         if (prof) HIP_TRY(hipEventRecord(ev[0], sc));
         launch_vad(va, sc);
         if (prof) HIP_TRY(hipEventRecord(ev[1], sc));
@@ -816,12 +859,12 @@ int sr_recognize_segments_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_
         d_vad = h->s_vad.p;
     }
     if ((rc = h->s_vad2.reserve(B))) return rc;
-    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * h->nc))) return rc;
     if (!d_scores) {
         if ((rc = h->s_scores.reserve((size_t)B * h->K * h->cfg.max_seg))) return rc;
         d_scores = h->s_scores.p;
     }
-    VadArgs va{d_pcm, pcm_stride, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, d_vad, nullptr, nullptr, h->frame_len};
+    VadArgs va = vad_args(h, d_pcm, pcm_stride, buf_len, h->noise_len, B, d_vad);
     launch_vad(va, s);
     for (uint32_t sg = 0; sg < h->cfg.max_seg; sg++) {
         launch_select_segment(d_vad, h->s_vad2.p, B, sg, h->cfg.max_frames, h->frame_len, h->hop, s);
@@ -850,28 +893,40 @@ static int stage_pcm(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uin
     return SR_OK;
 }
 
-int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
-                       sr_result *results, uint32_t *scores, int16_t *mfcc, sr_vad_rec *vad)
+// Host buffers -> results.  `packed` = false: u16 rows of pcm_stride SAMPLES; true: rows of 12-bit codes, two samples in
+// three bytes, row stride in BYTES (sr_recognize_batch_packed12).
+static int recognize_host(sr_engine *h, const void *pcm, uint64_t row_stride, bool packed, uint32_t buf_len, uint32_t B,
+                          sr_result *results, uint32_t *scores, int16_t *mfcc, sr_vad_rec *vad)
 {
     if (!h || !pcm || !results) return fail(SR_ERR_BAD_ARG, "null argument");
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
     if (B == 0) return SR_OK;
-    if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
+    const uint64_t src_row_bytes = packed ? ((uint64_t)(buf_len + 1) / 2) * 3 : (uint64_t)buf_len * 2;  // bytes that carry samples
+    const uint64_t src_pitch = packed ? row_stride : row_stride * 2;
+    if (src_row_bytes > src_pitch) return fail(SR_ERR_BAD_ARG, packed ? "row stride smaller than ceil(buf_len / 2) * 3 bytes" : "buf_len exceeds pcm_stride");
     ENTER_DEVICE(h);
     const uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
+    const uint64_t dpk = ds / 8 * 12;  // device pitch of a packed row: whole groups of 8 samples = 12 bytes
     int rc;
     if ((rc = h->s_pcm.reserve((size_t)B * ds))) return rc;
+    if (packed && (rc = h->s_pack.reserve((size_t)B * dpk + 16))) return rc;
     if ((rc = h->s_results.reserve(B))) return rc;
     if ((rc = h->s_vad.reserve(B))) return rc;
-    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * h->nc))) return rc;
     if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
     // The upload dominates (2*buf_len bytes per utterance over PCIe vs ~0.5 us of kernels): split the batch into
     // chunks and let the upload of chunk c+1 run on the copy stream while chunk c is processed on the compute
     // stream.  hipMemcpy2DAsync from pageable memory returns when the host buffer has been consumed, so the host
     // thread paces the copies; kernels are only enqueued.  Results come back once, after the last chunk.
     const uint32_t n_chunks = (B >= 2048) ? std::min<uint32_t>(16, B / 1024) : 1;
+    const uint8_t *src = (const uint8_t *)pcm;
     if (n_chunks <= 1 || h->profiling) {
-        HIP_TRY(hipMemcpy2D(h->s_pcm.p, ds * 2, pcm, pcm_stride * 2, (size_t)buf_len * 2, B, hipMemcpyHostToDevice));
+        if (packed) {
+            HIP_TRY(hipMemcpy2D(h->s_pack.p, dpk, src, src_pitch, src_row_bytes, B, hipMemcpyHostToDevice));
+            launch_unpack12(h->s_pack.p, dpk, h->s_pcm.p, ds, buf_len, B, nullptr);
+        } else {
+            HIP_TRY(hipMemcpy2D(h->s_pcm.p, ds * 2, src, src_pitch, src_row_bytes, B, hipMemcpyHostToDevice));
+        }
         rc = sr_recognize_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_results.p, h->s_scores.p, h->s_mfcc.p, h->s_vad.p,
                                     nullptr);
         if (rc) return rc;
@@ -887,13 +942,18 @@ int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
         const uint32_t per = (B + n_chunks - 1) / n_chunks;
         for (uint32_t c = 0, b0 = 0; b0 < B; c++, b0 += per) {
             const uint32_t n = std::min(per, B - b0);
-            HIP_TRY(hipMemcpy2DAsync(h->s_pcm.p + (size_t)b0 * ds, ds * 2, pcm + (size_t)b0 * pcm_stride, pcm_stride * 2,
-                                     (size_t)buf_len * 2, n, hipMemcpyHostToDevice, h->st_copy));
+            if (packed)
+                HIP_TRY(hipMemcpy2DAsync(h->s_pack.p + (size_t)b0 * dpk, dpk, src + (size_t)b0 * src_pitch, src_pitch, src_row_bytes, n,
+                                         hipMemcpyHostToDevice, h->st_copy));
+            else
+                HIP_TRY(hipMemcpy2DAsync(h->s_pcm.p + (size_t)b0 * ds, ds * 2, src + (size_t)b0 * src_pitch, src_pitch, src_row_bytes, n,
+                                         hipMemcpyHostToDevice, h->st_copy));
             HIP_TRY(hipEventRecord(h->ev_chunk[c], h->st_copy));
             HIP_TRY(hipStreamWaitEvent(h->st_comp, h->ev_chunk[c], 0));
+            if (packed) launch_unpack12(h->s_pack.p + (size_t)b0 * dpk, dpk, h->s_pcm.p + (size_t)b0 * ds, ds, buf_len, n, h->st_comp);
             rc = sr_recognize_batch_dev(h, h->s_pcm.p + (size_t)b0 * ds, ds, buf_len, n, h->s_results.p + b0,
                                         h->s_scores.p + (size_t)b0 * h->K,
-                                        h->s_mfcc.p + (size_t)b0 * h->cfg.max_frames * kCoef, h->s_vad.p + b0, h->st_comp);
+                                        h->s_mfcc.p + (size_t)b0 * h->cfg.max_frames * h->nc, h->s_vad.p + b0, h->st_comp);
             if (rc) {
                 (void)hipDeviceSynchronize();
                 return rc;
@@ -904,9 +964,21 @@ int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
     HIP_TRY(hipMemcpy(results, h->s_results.p, (size_t)B * sizeof(sr_result), hipMemcpyDeviceToHost));
     if (scores) HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
     if (mfcc)
-        HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * kCoef * 2, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * h->nc * 2, hipMemcpyDeviceToHost));
     if (vad) HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
     return SR_OK;
+}
+
+int sr_recognize_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                       sr_result *results, uint32_t *scores, int16_t *mfcc, sr_vad_rec *vad)
+{
+    return recognize_host(h, pcm, pcm_stride, false, buf_len, B, results, scores, mfcc, vad);
+}
+
+int sr_recognize_batch_packed12(sr_engine *h, const uint8_t *packed, uint64_t row_stride_bytes, uint32_t buf_len, uint32_t B,
+                                sr_result *results, uint32_t *scores, int16_t *mfcc, sr_vad_rec *vad)
+{
+    return recognize_host(h, packed, row_stride_bytes, true, buf_len, B, results, scores, mfcc, vad);
 }
 
 int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
@@ -963,7 +1035,7 @@ int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, u
     DevBuf<uint64_t> dm;
     if ((rc = dm.reserve((size_t)B * 16))) return rc;
     HIP_TRY(hipMemset(dm.p, 0, (size_t)B * 16 * 8));
-    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, h->s_vad.p, nullptr, dm.p, h->frame_len};
+    VadArgs a = vad_args(h, h->s_pcm.p, ds, buf_len, h->noise_len, B, h->s_vad.p, nullptr, dm.p);
     launch_vad(a, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
@@ -1012,10 +1084,10 @@ int sr_mfcc_batch_status(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride,
     int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
     if (rc) return rc;
     if ((rc = h->s_vad.reserve(B))) return rc;
-    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * kCoef))) return rc;
+    if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * h->nc))) return rc;
     HIP_TRY(hipMemcpy(h->s_vad.p, recs.data(), (size_t)B * sizeof(sr_vad_rec), hipMemcpyHostToDevice));
     if ((rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, B, h->s_vad.p, h->s_mfcc.p, nullptr))) return rc;
-    HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * kCoef * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * h->nc * 2, hipMemcpyDeviceToHost));
     return SR_OK;
 }
 
@@ -1034,8 +1106,8 @@ int sr_train_store(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint3
     if (!h || !pcm || !slot || !store) return fail(SR_ERR_BAD_ARG, "null argument");
     if (n == 0) return SR_OK;
     if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
-    if (stride_bytes < 4 + 2 * kCoef) return fail(SR_ERR_BAD_ARG, "slot stride too small for a v_ftr_tag");
-    const uint32_t slot_rows = (stride_bytes - 4) / (2 * kCoef);
+    if (stride_bytes < 4 + 2 * h->nc) return fail(SR_ERR_BAD_ARG, "slot stride too small for a v_ftr_tag");
+    const uint32_t slot_rows = (stride_bytes - 4) / (2 * h->nc);
     for (uint32_t i = 0; i < n; i++)
         if (slot[i] >= n_slots) return fail(SR_ERR_BAD_ARG, "slot index outside the store");  // Flash.C:22-26
     ENTER_DEVICE(h);
@@ -1043,7 +1115,7 @@ int sr_train_store(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint3
     int rc = stage_pcm(h, pcm, pcm_stride, buf_len, n, &ds);
     if (rc) return rc;
     if ((rc = h->s_vad.reserve(n))) return rc;
-    const size_t msz = (size_t)n * h->cfg.max_frames * kCoef;
+    const size_t msz = (size_t)n * h->cfg.max_frames * h->nc;
     if ((rc = h->s_mfcc.reserve(msz))) return rc;
     if ((rc = sr_vad_batch_dev(h, h->s_pcm.p, ds, buf_len, n, h->s_vad.p, nullptr))) return rc;
     if ((rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, n, h->s_vad.p, h->s_mfcc.p, nullptr))) return rc;
@@ -1062,7 +1134,7 @@ int sr_train_store(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint3
         const uint16_t sign = SR_SAVE_MASK, fr = (uint16_t)recs[i].frm_num;
         std::memcpy(dst, &sign, 2);
         std::memcpy(dst + 2, &fr, 2);
-        std::memcpy(dst + 4, &mf[(size_t)i * h->cfg.max_frames * kCoef], (size_t)fr * kCoef * 2);
+        std::memcpy(dst + 4, &mf[(size_t)i * h->cfg.max_frames * h->nc], (size_t)fr * h->nc * 2);
     }
     return SR_OK;
 }
@@ -1077,7 +1149,7 @@ int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames
         if (in_frames[b] > h->cfg.max_frames) return fail(SR_ERR_BAD_ARG, "in_frames exceeds max_frames");
     ENTER_DEVICE(h);
     int rc;
-    const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
+    const size_t msz = (size_t)B * h->cfg.max_frames * h->nc;
     if ((rc = h->s_mfcc.reserve(msz))) return rc;
     if ((rc = h->s_u32a.reserve(B))) return rc;
     if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
@@ -1101,6 +1173,7 @@ int sr_get_mdl_batch(sr_engine *h, const int16_t *in1, const uint32_t *n1, uint3
     if (!h || !in1 || !n1 || !in2 || !n2 || !mdl_frames || !dis || (mdl_rows && !mdl))
         return fail(SR_ERR_BAD_ARG, "null argument");
     if (P == 0) return SR_OK;
+    if (h->nc != (uint32_t)kCoef) return fail(SR_ERR_BAD_CONFIG, "get_mdl is built for 12-coefficient records");
     if (rows1 == 0 || rows2 == 0) return fail(SR_ERR_BAD_ARG, "rows1 / rows2 must be at least 1");
     for (uint32_t p = 0; p < P; p++)
         if (n1[p] > rows1 || n2[p] > rows2 || n1[p] > 0xFFFF || n2[p] > 0xFFFF)
@@ -1133,6 +1206,7 @@ int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_i
 {
     if (!h || !d_mfcc || !d_scores || (!d_in_frames && !d_vad)) return fail(SR_ERR_BAD_ARG, "null argument");
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
+    if (h->nc != (uint32_t)kCoef) return fail(SR_ERR_BAD_CONFIG, "the full-DP scorer is built for 12-coefficient records");
     if ((size_t)h->tpl_rows * 48 > 150 * 1024) return fail(SR_ERR_BAD_ARG, "templates too long for the LDS-staged DP kernel");
     ENTER_DEVICE(h);
     DtwArgs a = dtw_args(h, d_mfcc, d_vad, d_in_frames, B, d_scores, nullptr);
@@ -1151,7 +1225,7 @@ int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_fra
         if (in_frames[b] > h->cfg.max_frames) return fail(SR_ERR_BAD_ARG, "in_frames exceeds max_frames");
     ENTER_DEVICE(h);
     int rc;
-    const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
+    const size_t msz = (size_t)B * h->cfg.max_frames * h->nc;
     if ((rc = h->s_mfcc.reserve(msz))) return rc;
     if ((rc = h->s_u32a.reserve(B))) return rc;
     if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
@@ -1167,9 +1241,9 @@ int sr_delta_mfcc_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_re
                             uint32_t B, int16_t *d_delta, void *stream)
 {
     if (!h || !d_mfcc || !d_delta || (!d_vad && !d_frames)) return fail(SR_ERR_BAD_ARG, "null argument");
-    if ((uint64_t)B * h->cfg.max_frames * kCoef > 0xFFFFFFFFull * 256) return fail(SR_ERR_BAD_ARG, "batch too large");
+    if ((uint64_t)B * h->cfg.max_frames * h->nc > 0xFFFFFFFFull * 256) return fail(SR_ERR_BAD_ARG, "batch too large");
     ENTER_DEVICE(h);
-    launch_delta_mfcc(d_mfcc, d_vad, d_frames, B, h->cfg.max_frames, d_delta, (hipStream_t)stream);
+    launch_delta_mfcc(d_mfcc, d_vad, d_frames, B, h->cfg.max_frames, h->nc, d_delta, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SR_OK;
 }
@@ -1180,7 +1254,7 @@ int sr_delta_mfcc_batch(sr_engine *h, const int16_t *mfcc, const uint32_t *frame
     if (B == 0) return SR_OK;
     ENTER_DEVICE(h);
     int rc;
-    const size_t msz = (size_t)B * h->cfg.max_frames * kCoef;
+    const size_t msz = (size_t)B * h->cfg.max_frames * h->nc;
     if ((rc = h->s_mfcc.reserve(2 * msz))) return rc;
     if ((rc = h->s_u32a.reserve(B))) return rc;
     HIP_TRY(hipMemcpy(h->s_mfcc.p, mfcc, msz * 2, hipMemcpyHostToDevice));
@@ -1276,7 +1350,7 @@ int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, co
     if ((rc = h->s_vad.reserve(1))) return rc;
     if ((rc = h->s_atap.reserve(1))) return rc;
     HIP_TRY(hipMemcpy(h->s_atap.p, atap, sizeof(sr_atap), hipMemcpyHostToDevice));
-    VadArgs a{h->s_pcm.p, ds, buf_len, h->noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, h->s_atap.p, nullptr, h->frame_len};
+    VadArgs a = vad_args(h, h->s_pcm.p, ds, buf_len, h->noise_len, 1, h->s_vad.p, h->s_atap.p);
     launch_vad(a, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(rec, h->s_vad.p, sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
@@ -1292,7 +1366,7 @@ int engine_noise_atap(sr_engine *h, const uint16_t *noise, uint32_t n_len, sr_at
     int rc = stage_pcm(h, noise, n_len, n_len, 1, &ds);
     if (rc) return rc;
     if ((rc = h->s_vad.reserve(1))) return rc;
-    VadArgs a{h->s_pcm.p, ds, n_len, n_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, 1, h->s_vad.p, nullptr, nullptr, h->frame_len};
+    VadArgs a = vad_args(h, h->s_pcm.p, ds, n_len, n_len, 1, h->s_vad.p);
     launch_vad(a, nullptr);
     HIP_TRY(hipGetLastError());
     sr_vad_rec rec;

@@ -76,8 +76,8 @@ static void gen_tri(HostTables &t, const FrontEnd &fe)
 static void gen_dct(HostTables &t, const FrontEnd &fe)
 {
     const int nm = fe.n_mel;
-    t.dct.resize(kCoef * nm);
-    for (int h = 1; h <= kCoef; h++)
+    t.dct.resize(fe.n_coef * nm);
+    for (int h = 1; h <= fe.n_coef; h++)
         for (int j = 1; j <= nm; j++)
             t.dct[(h - 1) * nm + (j - 1)] = (int8_t)mround(std::cos(h * M_PI * (j - 0.5) / nm) * 100);
 }

@@ -21,10 +21,11 @@ constexpr int kTieMax = 32768;  // entries of the DTW tie-threshold table (roots
 // The two front ends the kernels are built for: the reference's (ADC.H:7, VAD.H:5-8, MFCC.H:7-13) and the
 // 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
 struct FrontEnd {
-    int fs, frame_len, hop, nfft, bins, n_mel;
+    int fs, frame_len, hop, nfft, bins, n_mel, n_coef;
+    bool generic;  // neither of the two specialised kernels: k_mfcc_gen + the VAD instance of the framing
 };
-constexpr FrontEnd kFrontRef = {8000, 160, 80, 1024, 512, 24};
-constexpr FrontEnd kFrontExt = {16000, 320, 160, 512, 256, 40};
+constexpr FrontEnd kFrontRef = {8000, 160, 80, 1024, 512, 24, 12, false};
+constexpr FrontEnd kFrontExt = {16000, 320, 160, 512, 256, 40, 12, false};
 
 struct HostTables {
     std::vector<uint16_t> hamm;      // [160]

@@ -39,6 +39,10 @@ def load_library():
     """dlopen libsr_engine.so (built by __graft_entry__.build() / csrc/Makefile)."""
     global _lib
     if _lib is None:
+        try:  # a process that also uses PyTorch must let torch load ITS HIP runtime first: libsr_engine.so then binds to the
+            import torch  # noqa: F401  same libamdhip64 (loaded the other way round, torch finds "no HIP GPUs")
+        except ImportError:
+            pass
         path = os.environ.get("SR_ENGINE_LIB", LIB_PATH)  # development override: A/B-ing two builds on one GPU box
         if not os.path.exists(path):
             raise SrError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -115,6 +119,7 @@ class Engine:
         self._check(self.L.sr_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.max_frames = max_frames
+        self.n_coef = cfg.n_coef  # 12 except for the generic front end
         self.noise_len = (cfg.fs // 1000) * cfg.noise_len_ms
 
     @classmethod
@@ -122,6 +127,7 @@ class Engine:
         """a view of an sr_engine handle somebody else owns (sr_multi_engine): same methods, never destroyed from here"""
         e = cls.__new__(cls)
         e.L, e.cfg, e.h, e.max_frames, e._borrowed = load_library(), cfg, C.c_void_p(handle), max_frames, True
+        e.n_coef = cfg.n_coef
         e.noise_len = (cfg.fs // 1000) * cfg.noise_len_ms
         return e
 
@@ -183,10 +189,23 @@ class Engine:
         K = self.n_templates
         res = np.zeros(B, dtype=RESULT_DTYPE)
         sc = np.zeros((B, K), dtype=np.uint32) if want_scores else None
-        mf = np.zeros((B, self.max_frames, N_COEF), dtype=np.int16) if want_mfcc else None
+        mf = np.zeros((B, self.max_frames, self.n_coef), dtype=np.int16) if want_mfcc else None
         vd = np.zeros(B, dtype=VAD_DTYPE) if want_vad else None
         self._check(self.L.sr_recognize_batch(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(buf_len), C.c_uint32(B),
                                               _vp(res), _vp(sc), _vp(mf), _vp(vd)))
+        return dict(results=res, scores=sc, mfcc=mf, vad=vd)
+
+    def recognize_packed12(self, packed, buf_len, want_scores=True, want_mfcc=True, want_vad=True):
+        """packed uint8 [B, row_bytes]: 12-bit codes, two samples in three bytes (pack12()); sr_recognize_batch_packed12."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        B, rb = packed.shape
+        K = self.n_templates
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        sc = np.zeros((B, K), dtype=np.uint32) if want_scores else None
+        mf = np.zeros((B, self.max_frames, self.n_coef), dtype=np.int16) if want_mfcc else None
+        vd = np.zeros(B, dtype=VAD_DTYPE) if want_vad else None
+        self._check(self.L.sr_recognize_batch_packed12(self.h, _vp(packed), C.c_uint64(rb), C.c_uint32(buf_len), C.c_uint32(B),
+                                                       _vp(res), _vp(sc), _vp(mf), _vp(vd)))
         return dict(results=res, scores=sc, mfcc=mf, vad=vd)
 
     def recognize_segments(self, pcm):
@@ -216,7 +235,7 @@ class Engine:
         start = np.ascontiguousarray(start, dtype=np.int32)
         end = np.ascontiguousarray(end, dtype=np.int32)
         mid = np.ascontiguousarray(mid, dtype=np.uint32)
-        out = np.zeros((B, self.max_frames, N_COEF), dtype=np.int16)
+        out = np.zeros((B, self.max_frames, self.n_coef), dtype=np.int16)
         n = np.zeros(B, dtype=np.uint32)
         self._check(self.L.sr_mfcc_batch(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B), _vp(start),
                                          _vp(end), _vp(mid), _vp(out), _vp(n)))
@@ -230,7 +249,7 @@ class Engine:
         start = np.ascontiguousarray(start, dtype=np.int32)
         end = np.ascontiguousarray(end, dtype=np.int32)
         mid = np.ascontiguousarray(mid, dtype=np.uint32)
-        out = np.zeros((B, self.max_frames, N_COEF), dtype=np.int16)
+        out = np.zeros((B, self.max_frames, self.n_coef), dtype=np.int16)
         n = np.zeros(B, dtype=np.uint32)
         st = np.zeros(B, dtype=np.uint32)
         self._check(self.L.sr_mfcc_batch_status(self.h, _vp(pcm), C.c_uint64(S), C.c_uint32(S), C.c_uint32(B), _vp(start),
@@ -240,7 +259,7 @@ class Engine:
     def dtw(self, in_mfcc, in_frames):
         """in_mfcc int16 [B, max_frames, 12] against the template store -> (scores [B,K], results [B])."""
         in_mfcc = np.ascontiguousarray(in_mfcc, dtype=np.int16)
-        assert in_mfcc.shape[1:] == (self.max_frames, N_COEF)
+        assert in_mfcc.shape[1:] == (self.max_frames, self.n_coef)
         in_frames = np.ascontiguousarray(in_frames, dtype=np.uint32)
         B = in_mfcc.shape[0]
         sc = np.zeros((B, self.n_templates), dtype=np.uint32)
@@ -251,7 +270,7 @@ class Engine:
     def dtw_dp(self, in_mfcc, in_frames):
         """OPT-IN non-reference scorer: full-DP DTW scores [B, K] (see sr_dtw_dp_batch)."""
         in_mfcc = np.ascontiguousarray(in_mfcc, dtype=np.int16)
-        assert in_mfcc.shape[1:] == (self.max_frames, N_COEF)
+        assert in_mfcc.shape[1:] == (self.max_frames, self.n_coef)
         in_frames = np.ascontiguousarray(in_frames, dtype=np.uint32)
         B = in_mfcc.shape[0]
         sc = np.zeros((B, self.n_templates), dtype=np.uint32)
@@ -294,7 +313,7 @@ class Engine:
         """EXTENSION (no reference counterpart): two-frame regression delta cepstra of B records [B, max_frames, 12]."""
         mfcc = np.ascontiguousarray(mfcc, dtype=np.int16)
         frames = np.ascontiguousarray(frames, dtype=np.uint32)
-        assert mfcc.shape[1:] == (self.max_frames, N_COEF)
+        assert mfcc.shape[1:] == (self.max_frames, self.n_coef)
         out = np.zeros_like(mfcc)
         self._check(self.L.sr_delta_mfcc_batch(self.h, _vp(mfcc), _vp(frames), C.c_uint32(len(frames)), _vp(out)))
         return out
@@ -312,7 +331,7 @@ class Engine:
         K = self.n_templates
         o = dict(results=torch.empty(B, 4, dtype=torch.int32, device=device))
         o["scores"] = torch.empty(B, K, dtype=torch.int32, device=device) if scores else None
-        o["mfcc"] = torch.empty(B, self.max_frames, N_COEF, dtype=torch.int16, device=device) if mfcc else None
+        o["mfcc"] = torch.empty(B, self.max_frames, self.n_coef, dtype=torch.int16, device=device) if mfcc else None
         o["vad"] = torch.empty(B, 12, dtype=torch.int32, device=device) if vad else None
         return o
 
@@ -337,7 +356,7 @@ class Engine:
         if stream is None:
             stream = torch.cuda.current_stream(pcm.device).cuda_stream
         vad = torch.empty(B, 12, dtype=torch.int32, device=pcm.device)
-        mfcc = torch.empty(B, self.max_frames, N_COEF, dtype=torch.int16, device=pcm.device)
+        mfcc = torch.empty(B, self.max_frames, self.n_coef, dtype=torch.int16, device=pcm.device)
         self._check(self.L.sr_vad_batch_dev(self.h, _vp(pcm), C.c_uint64(S),
                                             C.c_uint32(S if buf_len is None else buf_len), C.c_uint32(B), _vp(vad),
                                             C.c_void_p(stream)))
@@ -358,6 +377,22 @@ class Engine:
         n = C.c_uint32(0)
         self._check(self.L.sr_get_stage_launches(self.h, C.byref(n)))
         return dict(vad=ms[0], mfcc=ms[1], dtw=ms[2], argmin=ms[3], total=ms[4], launches_per_call=n.value)
+
+
+def pack12(pcm):
+    """uint16 [B, S] 12-bit ADC codes -> uint8 [B, ceil(S / 2) * 3]: sample 2i = b[3i] | (b[3i+1] & 0x0F) << 8,
+    sample 2i+1 = b[3i+1] >> 4 | b[3i+2] << 4 (the layout sr_recognize_batch_packed12 reads)"""
+    pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+    assert pcm.max(initial=0) < 4096, "12-bit codes only"
+    B, S = pcm.shape
+    if S & 1:
+        pcm = np.concatenate([pcm, np.zeros((B, 1), np.uint16)], 1)
+    a, b = pcm[:, 0::2].astype(np.uint32), pcm[:, 1::2].astype(np.uint32)
+    out = np.empty((B, a.shape[1], 3), np.uint8)
+    out[:, :, 0] = a & 0xFF
+    out[:, :, 1] = (a >> 8) | ((b & 0xF) << 4)
+    out[:, :, 2] = b >> 4
+    return out.reshape(B, -1)
 
 
 def results_from_torch(t):

@@ -60,6 +60,20 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# configurations of the GENERIC front end (round 4: the reference's compile-time constants as run-time values) that the
+# tests run; none is one of the two specialised front ends
+GENERIC_CONFIGS = [
+    # engine keywords                                                              oracle keywords
+    (dict(n_mel=26, n_coef=13),                                                    dict(n_mel=26, n_coef=13)),
+    (dict(fs=16000, n_mel=40),                                                     dict(fs=16000, n_mel=40)),
+    (dict(frame_time_ms=32, frame_mov_ms=16, n_mel=20, n_coef=10, noise_len_ms=480),
+     dict(frame_time=32, frame_mov_t=16, n_mel=20, n_coef=10, noise_len_t=480)),
+    (dict(frame_time_ms=30, frame_mov_ms=15, n_coef=16),                           dict(frame_time=30, frame_mov_t=15, n_coef=16)),
+    (dict(fs=16000, frame_time_ms=32, frame_mov_ms=16, n_mel=64, n_coef=8, noise_len_ms=480),
+     dict(fs=16000, frame_time=32, frame_mov_t=16, n_mel=64, n_coef=8, noise_len_t=480)),
+]
+
+
 class Oracle:
     def __init__(self, max_frames=119, **kw):
         build()

@@ -854,13 +854,41 @@ def test_bench_other_configs_and_roofline_keys():
     assert r["overlapped"]["launches_per_step"] >= 2 and r["overlapped"]["utterances_per_launch"] < 8192
     assert j["cpu_baseline"]["gpu_results_identical_on_sample"] is True
     oc = j["other_configs"]
-    assert len(oc) == 2 and "configs[4] EXTENSION" in oc[1]["workload"] and "10 templates" in oc[0]["workload"]
-    for e in oc:
+    assert len(oc) == 3 and "configs[4] EXTENSION" in oc[1]["workload"] and "10 templates" in oc[0]["workload"]
+    for e in oc[:2]:
         assert e["value"] > 0 and e["parity_on_sample"]["identical"] is True and e["kernel_ms_isolated"]["mfcc"] > 0
         assert e["top1_word_accuracy"] == 1.0
+    dp = oc[2]  # the opt-in NON-REFERENCE full-DP scorer, timed alone
+    assert "NON-REFERENCE" in dp["workload"] and dp["kernel"] == "k_dtw_dp_band<8>" and dp["parity_on_sample"]["identical"] is True
+    assert dp["pairs_per_s"] > 0 and 15000 < dp["cells_per_pair"] < 30000
+    lat = j["latency"]  # one call of the drop-in symbols next to the reference's objects on one host core
+    assert lat["spch_recg_us"] > 0 and lat["spch_recg_identical"] is True and lat["dtw_identical"] is True
+    assert set(lat["sr_recognize_batch_dev_B1_kernel_us"]) == {"vad", "mfcc", "dtw", "argmin", "total"}
+    assert j["roofline"]["traffic_stale"] in (True, False) and "sclk" in j
 
 
 # ----------------------------------------------------------------------------- SURVEY 8(f) rows
+def test_packed12_host_transport_matches_the_u16_call(eng119, golden):
+    """sr_recognize_batch_packed12: 12-bit ADC codes packed two samples in three bytes, unpacked on the device -- identical
+    results, scores, MFCC and VAD records to the u16 call on the golden captures (odd and even buffer lengths, a padded row
+    stride, and a batch large enough for the chunked upload path)."""
+    from stm32_speech_recognition_amd.engine import pack12
+    eng119.set_templates_store(golden["store"])
+    pcm = golden["pcm"]
+    for S in (pcm.shape[1], pcm.shape[1] - 1, pcm.shape[1] - 5):
+        p = np.ascontiguousarray(pcm[:, :S])
+        want = eng119.recognize(p)
+        pk = pack12(p)
+        pk = np.concatenate([pk, np.full((len(pk), 7), 0xEE, np.uint8)], 1)  # row stride larger than the payload
+        got = eng119.recognize_packed12(pk, S)
+        for k in ("results", "scores", "mfcc", "vad"):
+            assert np.array_equal(got[k], want[k]), (S, k)
+    big = np.tile(pcm, (200, 1))[:2300]  # >= 2048 rows: uploads in chunks that overlap the kernels
+    want = eng119.recognize(big, want_mfcc=False, want_vad=False)
+    got = eng119.recognize_packed12(pack12(big), big.shape[1], want_mfcc=False, want_vad=False)
+    assert np.array_equal(got["results"], want["results"]) and np.array_equal(got["scores"], want["scores"])
+
+
 def test_recognize_segments_matches_golden(eng119, golden):
     """multi-segment recognition against the reference objects' per-segment get_mfcc + dtw"""
     eng119.set_templates_store(golden["store"])
@@ -1093,6 +1121,71 @@ def test_extension_front_end_segments_at_odd_and_first_samples():
                 wrong.append((b, int(starts[b]), [int(f) for f in np.nonzero((mf[b, :nn] != m).any(1))[0][:6]]))
         assert not wrong, (cfg, wrong)  # (record, start sample, first differing frames)
         eng.close()
+
+
+@pytest.mark.parametrize("ci", range(len(ol.GENERIC_CONFIGS)))
+def test_generic_front_end_matches_oracle(ci):
+    """GENERIC front end (round 4): the reference's compile-time constants (MFCC.H:7-16, VAD.H:4-8, ADC.H:7-11) as
+    run-time configuration -- other sampling rates, framings, filter counts and feature widths -- through k_mfcc_gen, the
+    VAD instance of the framing and (for feature rows that are not 12 wide) k_dtw_gen.  Whole path against the
+    parametrised oracle: thresholds, every VAD segment, frame counts, MFCC s16, all scores, argmin; silent and
+    over-long captures included.  No reference counterpart for the constants; every arithmetic rule is the reference's."""
+    from stm32_speech_recognition_amd import Engine
+    ekw, okw = ol.GENERIC_CONFIGS[ci]
+    rng = np.random.default_rng(400 + ci)
+    maxf, K, B = 150, 14, 72
+    orc = ol.Oracle(max_frames=maxf, **okw)
+    eng = Engine(max_frames=maxf, device=0, **ekw)
+    rate = 2 if ekw.get("fs", 8000) == 16000 else 1
+    bank = synth.word_bank(7)
+    S = synth.buf_len_for(120, rate) + 4000  # room for the longer noise heads (480 ms)
+    nl = orc.noise_len
+
+    def captures(n, lo, hi, seed):
+        fr = [int(v) for v in rng.integers(lo, hi, n)]
+        p = synth.as_u16_numpy(synth.make_utterances(rng.integers(0, 7, n), fr, seed=seed, bank=bank, rate=rate, S=S))
+        if nl > 2400 * rate:  # the generator's quiet head is 300 ms: stretch it with more of the same noise
+            pad = (2048 + rng.normal(0, 8, (n, nl - 2400 * rate))).astype(np.uint16)
+            p = np.concatenate([pad, p], 1)[:, :S]
+        return np.ascontiguousarray(p)
+
+    tp = captures(K, 30, 110, 61)
+    nc = orc.n_coef
+    tm, tf = np.zeros((K, maxf + 1, nc), np.int16), np.zeros(K, np.uint32)
+    for k in range(K):
+        rc, a = orc.noise_atap(tp[k])
+        seg = orc.vad(tp[k], a)
+        assert seg[1] >= 0, k
+        n, m = orc.mfcc(tp[k], seg[0], seg[1], a)
+        tm[k, :n], tf[k] = m, n
+    assert (tf > 0).all() and len(set(tf.tolist())) > 4
+    valid = np.ones(K, np.uint8)
+    valid[2] = 0
+    pcm = captures(B, 20, 125, 62)
+    pcm[5] = 2048
+    pcm[6] = captures(1, 170, 171, 63)[0] if synth.buf_len_for(170, rate) + 4000 <= S else pcm[6]
+    eng.set_templates_dense(tm, tf, valid)
+    out = eng.recognize(pcm)
+    tpl = orc.make_templates(tm, tf, valid)
+    ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
+    for b in range(B):
+        rc, a = orc.noise_atap(pcm[b])
+        seg = orc.vad(pcm[b], a)
+        v = out["vad"][b]
+        assert (v["mid_val"], v["n_thl"], v["z_thl"], v["s_thl"]) == a.astuple(), b
+        assert np.array_equal(v["seg"], seg), b
+    assert np.array_equal(out["results"]["status"], ores["status"]) and np.array_equal(out["results"]["frm_num"], ores["frm_num"])
+    assert out["mfcc"].shape == omf.shape == (B, maxf, nc) and np.array_equal(out["mfcc"], omf)
+    assert np.array_equal(out["scores"], osc)
+    for f in ("best_tpl", "min_dis"):
+        assert np.array_equal(out["results"][f], ores[f]), f
+    assert (ores["status"] == 0).sum() > B // 2 and ores["status"][5] == ol.ST_VAD_FAIL and len(set(ores["frm_num"].tolist())) > 10
+    assert (osc[:, 2] == ol.DIS_ERR).all() and (osc != ol.DIS_ERR).sum() > B
+    # the device-resident entry point and template training run the same kernels
+    if nc == 12:
+        d = eng.delta_mfcc(out["mfcc"], out["results"]["frm_num"])
+        assert d.shape == out["mfcc"].shape
+    eng.close()
 
 
 def test_extension_front_end_matches_its_oracle():

@@ -110,6 +110,22 @@ def test_product_tables_equal_oracle_tables(oracle):
     assert (f(thr[1:2219]) >= m).all() and (f(thr[1:2219] - 1) < m).all()
 
 
+def test_generic_front_end_tables_and_config_gate():
+    """GENERIC front end (the reference's #define constants as run-time values): the product's table generator equals the
+    oracle's for every tested configuration (host-only sr_build_tables), and sr_build_tables / sr_create refuse what no
+    kernel is built for with SR_ERR_BAD_CONFIG."""
+    from stm32_speech_recognition_amd import engine
+    for ekw, okw in ol.GENERIC_CONFIGS:
+        t, o = engine.build_tables(**ekw), ol.Oracle(max_frames=64, **okw).tables()
+        for key in ("hamm", "tri_cen", "tri_odd", "tri_even", "dct"):
+            assert t[key].shape == o[key].shape and np.array_equal(t[key].astype(np.int64), o[key].astype(np.int64)), (ekw, key)
+    for bad in (dict(nfft=512), dict(nfft=2048), dict(fs=8001), dict(frame_time_ms=25), dict(frame_time_ms=20, frame_mov_ms=5),
+                dict(n_mel=25), dict(n_mel=66), dict(n_mel=2), dict(n_coef=0), dict(n_coef=17), dict(fs=16000, nfft=512),
+                dict(fs=44000, frame_time_ms=20, frame_mov_ms=10)):
+        with pytest.raises(engine.SrError, match="error 2"):
+            engine.build_tables(**bad)
+
+
 def test_preemphasis_float_form_is_exact():
     """MFCC.C:119 multiplies the previous sample by hp_ratio = 95/100 in integer arithmetic (p*95/100, truncated toward
     zero).  The frame kernels evaluate it as (int)((float)p * 0.95000005f) -- convert, IEEE multiply, truncating convert --
