@@ -143,24 +143,30 @@ __device__ __forceinline__ uint32_t add_sat(uint32_t a, uint32_t b)
     asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ int wave_min_i32(int v)
+// wave-wide minimum / maximum of a signed value, result uniform (SGPR): a prefix scan inside each row of 16 lanes by DPP
+// row shifts (a lane without a source keeps its own value), then the four row results (lanes 15, 31, 47, 63) are read
+// back to the scalar unit.  Four DPP operations + four v_readlane per reduction; the ds_bpermute butterflies of
+// __shfl_xor cost six LDS round trips each, which is what a strip's set-up waited for.
+template <bool MAX>
+__device__ __forceinline__ int wave_reduce_i32(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(v, d, 64);
-        v = o < v ? o : v;
+#define SR_DP_STEP(ctrl)                                                                  \
+    {                                                                                     \
+        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xF, 0xF, false);           \
+        v = MAX ? (o > v ? o : v) : (o < v ? o : v);                                      \
     }
-    return v;
+    SR_DP_STEP(0x111)  // row_shr:1
+    SR_DP_STEP(0x112)  // row_shr:2
+    SR_DP_STEP(0x114)  // row_shr:4
+    SR_DP_STEP(0x118)  // row_shr:8
+#undef SR_DP_STEP
+    const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31), c = __builtin_amdgcn_readlane(v, 47),
+              d = __builtin_amdgcn_readlane(v, 63);
+    const int ab = MAX ? (a > b ? a : b) : (a < b ? a : b), cd = MAX ? (c > d ? c : d) : (c < d ? c : d);
+    return MAX ? (ab > cd ? ab : cd) : (ab < cd ? ab : cd);
 }
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_min_i32(int v) { return wave_reduce_i32<false>(v); }
+__device__ __forceinline__ int wave_max_i32(int v) { return wave_reduce_i32<true>(v); }
 
 template <int G, int kDpWaves>  // lanes per pair, waves per workgroup
 __global__ void __launch_bounds__(64 * kDpWaves) k_dtw_dp_band(const DpBandArgs a)
@@ -325,7 +331,9 @@ static uint32_t dp_band_lds(uint32_t tpl_rows, int G, int waves, uint32_t *rows_
     if (rows_pad) *rows_pad = rp;
     return rp * 32u + (uint32_t)(waves * (64 / G)) * rp * 4u + 32u;
 }
-static int dp_waves_for(int G) { return G == 4 ? 2 : 4; }  // 64 / G * waves = 32 boundary columns per workgroup (16 at G = 16)
+// waves per workgroup.  Two-wave workgroups were measured and dropped (G = 4: 177 ms against 120 with four waves although
+// three of them fit a CU instead of one: their waves pile up on two of the four SIMDs)
+static int dp_waves_for(int G) { (void)G; return 4; }
 
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s)
 {
@@ -333,9 +341,9 @@ void launch_dtw_dp(const DtwArgs &a, hipStream_t s)
     int G = (int)a.dp_lanes;  // 0 = default
     if (G != 1 && G != 4 && G != 8 && G != 16) G = 8;
     uint32_t rp = 0;
-    if (G != 1 && (!a.tplR || dp_band_lds(a.tpl_rows, G, dp_waves_for(G), &rp) > 80u * 1024u)) {
+    if (G != 1 && (!a.tplR || dp_band_lds(a.tpl_rows, G, dp_waves_for(G), &rp) > 150u * 1024u)) {
         G = 16;  // fewer pairs per wave: fewer boundary columns
-        if (!a.tplR || dp_band_lds(a.tpl_rows, G, dp_waves_for(G), &rp) > 80u * 1024u) G = 1;
+        if (!a.tplR || dp_band_lds(a.tpl_rows, G, dp_waves_for(G), &rp) > 150u * 1024u) G = 1;
     }
     if (G == 1) {
         const size_t lds = (size_t)a.tpl_rows * 32 + (size_t)4 * a.tpl_rows * 4;
@@ -347,7 +355,7 @@ void launch_dtw_dp(const DtwArgs &a, hipStream_t s)
     DpBandArgs ba{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, rp};
     const uint32_t per_wg = (uint32_t)(W * (64 / G));
     const dim3 grid(a.K, (a.B + per_wg - 1) / per_wg), block(64 * W);
-    if (G == 4) hipLaunchKernelGGL((k_dtw_dp_band<4, 2>), grid, block, lds, s, ba);
+    if (G == 4) hipLaunchKernelGGL((k_dtw_dp_band<4, 4>), grid, block, lds, s, ba);
     else if (G == 8) hipLaunchKernelGGL((k_dtw_dp_band<8, 4>), grid, block, lds, s, ba);
     else hipLaunchKernelGGL((k_dtw_dp_band<16, 4>), grid, block, lds, s, ba);
 }
