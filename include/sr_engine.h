@@ -47,10 +47,17 @@ extern "C" {
 #define SR_SAVE_MASK 12345u    /* save_mask, Flash.H:11 */
 
 /* ------------------------------------------------------------------ configuration
- * The kernels are built for TWO front ends and sr_create accepts exactly those (SR_ERR_BAD_CONFIG otherwise):
- *   reference   fs 8000, 20/10 ms framing (160/80 samples), nfft 1024, 24 Mel, 12 MFCC   (ADC.H, VAD.H, MFCC.H)
+ * The reference's compile-time constants (ADC.H:7-11, VAD.H:4-8, MFCC.H:7-16) as a run-time configuration.  Two front ends
+ * have specialised kernels:
+ *   reference   fs 8000, 20/10 ms framing (160/80 samples), nfft 1024, 24 Mel, 12 MFCC   (the firmware's constants)
  *   extension   fs 16000, 20/10 ms framing (320/160 samples), nfft 512, 40 Mel, 12 MFCC   (no reference counterpart)
- * What is free at run time: max_frames (2..16383), noise_len_ms (a multiple of 60), max_seg (1..3), device. */
+ * Every other accepted configuration runs the GENERIC front end (same arithmetic rules, tables from the same formulas, about
+ * 4x slower per frame; no reference counterpart for the constants):
+ *   nfft 1024; fs a multiple of 1000 Hz; frame_time_ms = 2 * frame_mov_ms with a frame of 160, 240, 256, 320, 400 or 512
+ *   samples; n_mel even, 4..64; n_coef 1..16 (feature records are n_coef wide everywhere: mfcc[B][max_frames][n_coef],
+ *   template rows, slot images; sr_get_mdl_batch and the full-DP scorer require 12).
+ * Anything else: SR_ERR_BAD_CONFIG.  Free in every configuration: max_frames (2..16383), noise_len_ms (a multiple of 30 ms
+ * that holds whole frames), max_seg (1..3), device. */
 typedef struct sr_config {
     uint32_t fs;            /* ADC.H:7       8000 */
     uint32_t frame_time_ms; /* VAD.H:5       20  -> frame_len 160 */
