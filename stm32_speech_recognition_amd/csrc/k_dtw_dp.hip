@@ -347,17 +347,35 @@ void launch_dtw_dp(const DtwArgs &a, hipStream_t s)
     }
     if (G == 1) {
         const size_t lds = (size_t)a.tpl_rows * 32 + (size_t)4 * a.tpl_rows * 4;
-        hipLaunchKernelGGL(k_dtw_dp_wave64, dim3(a.K, (a.B + 3) / 4), dim3(256), lds, s, a);
+        for (uint32_t b0 = 0; b0 < a.B; b0 += 65535u * 4u) {  // grid.y <= 65 535
+            DtwArgs sa = a;
+            sa.B = (a.B - b0 < 65535u * 4u) ? a.B - b0 : 65535u * 4u;
+            sa.mfcc = a.mfcc + (size_t)b0 * a.max_frames * kCoef;
+            sa.vad = a.vad ? a.vad + b0 : nullptr;
+            sa.in_frames = a.in_frames ? a.in_frames + b0 : nullptr;
+            sa.scores = a.scores + (size_t)b0 * a.K;
+            hipLaunchKernelGGL(k_dtw_dp_wave64, dim3(a.K, (sa.B + 3) / 4), dim3(256), lds, s, sa);
+        }
         return;
     }
     const int W = dp_waves_for(G);
     const size_t lds = dp_band_lds(a.tpl_rows, G, W, &rp);
-    DpBandArgs ba{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, rp};
     const uint32_t per_wg = (uint32_t)(W * (64 / G));
-    const dim3 grid(a.K, (a.B + per_wg - 1) / per_wg), block(64 * W);
-    if (G == 4) hipLaunchKernelGGL((k_dtw_dp_band<4, 4>), grid, block, lds, s, ba);
-    else if (G == 8) hipLaunchKernelGGL((k_dtw_dp_band<8, 4>), grid, block, lds, s, ba);
-    else hipLaunchKernelGGL((k_dtw_dp_band<16, 4>), grid, block, lds, s, ba);
+    // the utterance blocks are the grid's second dimension (<= 65 535): larger batches go out in slices
+    const uint32_t slice = 65535u * per_wg;
+    for (uint32_t b0 = 0; b0 < a.B; b0 += slice) {
+        DtwArgs sa = a;
+        sa.B = (a.B - b0 < slice) ? a.B - b0 : slice;
+        sa.mfcc = a.mfcc + (size_t)b0 * a.max_frames * kCoef;
+        sa.vad = a.vad ? a.vad + b0 : nullptr;
+        sa.in_frames = a.in_frames ? a.in_frames + b0 : nullptr;
+        sa.scores = a.scores + (size_t)b0 * a.K;
+        DpBandArgs ba{sa, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, rp};
+        const dim3 grid(a.K, (sa.B + per_wg - 1) / per_wg), block(64 * W);
+        if (G == 4) hipLaunchKernelGGL((k_dtw_dp_band<4, 4>), grid, block, lds, s, ba);
+        else if (G == 8) hipLaunchKernelGGL((k_dtw_dp_band<8, 4>), grid, block, lds, s, ba);
+        else hipLaunchKernelGGL((k_dtw_dp_band<16, 4>), grid, block, lds, s, ba);
+    }
 }
 
 }  // namespace sr
