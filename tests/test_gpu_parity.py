@@ -1349,7 +1349,7 @@ def test_argument_checks_and_edge_sizes(golden):
         dev_hook("no_such_hook", 1)
     with pytest.raises(SrError, match="lanes per pair"):
         e.set_dp_lanes(3)
-    # a forced DTW geometry that cannot fit the CU's LDS is ignored, not launched: results unchanged
+    # a forced DTW geometry (development hooks: 16 utterances per workgroup, the whole tie table) gives the same results
     dev_hook("dtw_u", 16)
     dev_hook("dtw_tie_g", 32768)
     try:
