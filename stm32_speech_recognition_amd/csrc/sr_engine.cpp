@@ -182,7 +182,8 @@ void sr_default_config(sr_config *c)
 // Two front ends have specialised kernels: the reference's (8 kHz, 160/80 framing, 1024-point FFT, 24 Mel, 12 MFCC) and the
 // 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).  Every other accepted
 // configuration runs the GENERIC front end (k_mfcc_gen + the VAD instance of its framing; round 4): the reference's
-// compile-time constants (MFCC.H:7-16, VAD.H:4-8, ADC.H:7-11) as run-time values -- any fs that is a multiple of 1000 Hz,
+// compile-time constants (MFCC.H:7-16, VAD.H:4-8, ADC.H:7-11) as run-time values -- any fs that is a multiple of 4000 Hz
+// (the VAD kernel reads the 30 ms blocks of noise_atap, VAD.C:48-63, eight samples at a time),
 // 1024-point transform, frame_time = 2 * frame_mov with a framing the VAD kernel is instantiated for (frame_len 160, 240,
 // 256, 320, 400, 512 samples), an even number of 4..64 Mel filters, 1..16 coefficients.
 static int front_end_of(const sr_config *cfg, FrontEnd *fe)
@@ -194,9 +195,9 @@ static int front_end_of(const sr_config *cfg, FrontEnd *fe)
         return SR_OK;
     }
     const char *what = "supported: fs=8000/nfft=1024/24 Mel/12 MFCC (reference), fs=16000/nfft=512/40 Mel/12 MFCC (extension), or the generic "
-                       "front end: nfft=1024, fs a multiple of 1000, frame_time_ms = 2*frame_mov_ms with frame_len in {160,240,256,320,400,512}, "
+                       "front end: nfft=1024, fs a multiple of 4000, frame_time_ms = 2*frame_mov_ms with frame_len in {160,240,256,320,400,512}, "
                        "n_mel even 4..64, n_coef 1..16";
-    if (cfg->nfft != 1024 || cfg->fs == 0 || cfg->fs % 1000 || cfg->fs > 1000000) return fail(SR_ERR_BAD_CONFIG, what);
+    if (cfg->nfft != 1024 || cfg->fs == 0 || cfg->fs % 4000 || cfg->fs > 1000000) return fail(SR_ERR_BAD_CONFIG, what);
     const uint32_t fl = cfg->fs / 1000 * cfg->frame_time_ms, mov = cfg->fs / 1000 * cfg->frame_mov_ms;
     if (cfg->frame_time_ms != 2 * cfg->frame_mov_ms || fl < 2 || fl > 1024 || !vad_framing_supported(fl, fl - mov))
         return fail(SR_ERR_BAD_CONFIG, what);

@@ -71,6 +71,13 @@ GENERIC_CONFIGS = [
     (dict(frame_time_ms=30, frame_mov_ms=15, n_coef=16),                           dict(frame_time=30, frame_mov_t=15, n_coef=16)),
     (dict(fs=16000, frame_time_ms=32, frame_mov_ms=16, n_mel=64, n_coef=8, noise_len_ms=480),
      dict(fs=16000, frame_time=32, frame_mov_t=16, n_mel=64, n_coef=8, noise_len_t=480)),
+    # the edges of the accepted ranges: the fewest filters / one coefficient at an odd rate; the longest frame, most filters
+    (dict(fs=12000, n_mel=4, n_coef=1),
+     dict(fs=12000, n_mel=4, n_coef=1)),
+    (dict(fs=20000, n_mel=30, n_coef=12),
+     dict(fs=20000, n_mel=30, n_coef=12)),
+    (dict(frame_time_ms=64, frame_mov_ms=32, n_mel=64, n_coef=16, noise_len_ms=960),
+     dict(frame_time=64, frame_mov_t=32, n_mel=64, n_coef=16, noise_len_t=960)),
 ]
 
 

@@ -1138,7 +1138,7 @@ def test_generic_front_end_matches_oracle(ci):
     eng = Engine(max_frames=maxf, device=0, **ekw)
     rate = 2 if ekw.get("fs", 8000) == 16000 else 1
     bank = synth.word_bank(7)
-    S = synth.buf_len_for(120, rate) + 4000  # room for the longer noise heads (480 ms)
+    S = synth.buf_len_for(120, rate) + 8000  # room for the longer noise heads (up to 960 ms)
     nl = orc.noise_len
 
     def captures(n, lo, hi, seed):
@@ -1163,7 +1163,7 @@ def test_generic_front_end_matches_oracle(ci):
     valid[2] = 0
     pcm = captures(B, 20, 125, 62)
     pcm[5] = 2048
-    pcm[6] = captures(1, 170, 171, 63)[0] if synth.buf_len_for(170, rate) + 4000 <= S else pcm[6]
+    pcm[6] = captures(1, 170, 171, 63)[0] if synth.buf_len_for(170, rate) + 8000 <= S else pcm[6]
     eng.set_templates_dense(tm, tf, valid)
     out = eng.recognize(pcm)
     tpl = orc.make_templates(tm, tf, valid)

@@ -119,7 +119,7 @@ def test_generic_front_end_tables_and_config_gate():
         t, o = engine.build_tables(**ekw), ol.Oracle(max_frames=64, **okw).tables()
         for key in ("hamm", "tri_cen", "tri_odd", "tri_even", "dct"):
             assert t[key].shape == o[key].shape and np.array_equal(t[key].astype(np.int64), o[key].astype(np.int64)), (ekw, key)
-    for bad in (dict(nfft=512), dict(nfft=2048), dict(fs=8001), dict(frame_time_ms=25), dict(frame_time_ms=20, frame_mov_ms=5),
+    for bad in (dict(nfft=512), dict(nfft=2048), dict(fs=8001), dict(fs=10000, frame_time_ms=40, frame_mov_ms=20), dict(frame_time_ms=25), dict(frame_time_ms=20, frame_mov_ms=5),
                 dict(n_mel=25), dict(n_mel=66), dict(n_mel=2), dict(n_coef=0), dict(n_coef=17), dict(fs=16000, nfft=512),
                 dict(fs=44000, frame_time_ms=20, frame_mov_ms=10)):
         with pytest.raises(engine.SrError, match="error 2"):
