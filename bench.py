@@ -180,15 +180,24 @@ def make_templates(eng, bank, Kt, n_words, rate, dev):
 
 
 class ClockSampler:
-    """shader clock during the timed region, from sysfs (/sys/class/drm/card*/device/pp_dpm_sclk: the line marked `*` is
-    the current level; on MI300-class parts level 1 carries the live frequency).  Sampled every 20 ms on a host thread;
-    with several cards visible in sysfs the busiest one (highest clock) of each sample is taken -- the container exposes
-    one GPU to HIP but sysfs may list the whole node.  None when sysfs is not readable."""
+    """shader clock of THIS process's GPU during the timed region, from sysfs (/sys/class/drm/cardN/device/pp_dpm_sclk: the
+    line marked `*` is the current level; on MI300-class parts level 1 carries the live frequency).  The card is found by
+    the PCI address HIP reports for the device (sysfs lists every GPU of the node, also the ones other tenants are using).
+    Sampled every 20 ms on a host thread; summary() is None when the card or the file cannot be found."""
 
-    def __init__(self, period=0.02):
+    def __init__(self, period=0.02, device=None):
         import glob
         import threading
-        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.files = []
+        try:
+            dev = torch.cuda.current_device() if device is None else device
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+                if os.path.basename(os.path.realpath(os.path.dirname(f))).lower().startswith(want):
+                    self.files = [f]
+        except Exception:
+            self.files = []
         self.period, self.samples, self._stop = period, [], threading.Event()
         self._th = threading.Thread(target=self._run, daemon=True) if self.files else None
 
@@ -226,7 +235,7 @@ class ClockSampler:
             return None
         a = np.array(self.samples)
         return {"mean_mhz": float(a.mean()), "min_mhz": float(a.min()), "max_mhz": float(a.max()), "samples": int(a.size),
-                "source": "sysfs pp_dpm_sclk, 20 ms period, during the timed steps"}
+                "source": f"sysfs {self.files[0]}, {int(self.period * 1e3)} ms period, during the timed region"}
 
 
 FORCE_DIST = False  # test hook SR_BENCH_FORCE_DIST=1: initialise the process group and run the exchange even at N = 1
@@ -503,7 +512,9 @@ def latency_block(local_rank, n_utt=64):
 
     def f_spch(i):
         g[i] = compat.spch_recg(pcm[i])
-    out["spch_recg_us"] = us(f_spch, n_utt)
+    with ClockSampler(period=0.002) as clk:  # what the shader clock does under one-call-at-a-time load
+        out["spch_recg_us"] = us(f_spch, n_utt)
+    out["sclk_during_spch_recg"] = clk.summary()
     if ref is not None:
         def f_rspch(i):
             r[i] = ref.spch_recg(pcm[i], store)
