@@ -146,22 +146,41 @@ __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
 }
 
 // ---- k_dtw_gen: the same walk for feature rows of any width (GENERIC front end, n_coef != 12) -----------------------
-// One lane per pair, rows read coefficient by coefficient from global memory (rows of an odd number of s16 are only
-// 2-byte aligned), get_dis as written in DTW.C:45-62.  Slow and simple: stores with 12 coefficients never come here.
-__device__ __forceinline__ uint32_t get_dis_n(const int16_t *pa, const int16_t *pb, uint32_t nc)
+// One lane per pair.  A row of n_coef <= 16 coefficients lives in eight registers as packed pairs (zero-padded: the pad
+// contributes nothing to get_dis' sum of squares, DTW.C:45-62) with its squared norm; rows are fetched coefficient by
+// coefficient (rows of an odd number of s16 are only 2-byte aligned) when the walk advances, and a distance is the norm
+// sum minus twice eight v_dot2_i32_i16 -- the arithmetic of dtw_pair above in the same u32 ring.  Stores with 12
+// coefficients never come here (k_dtw_lds / k_dtw).
+struct Frame16 {
+    uint32_t w[8];
+    uint32_t n;
+};
+__device__ __forceinline__ Frame16 load_frame_n(const int16_t *p, uint32_t nc)
 {
-    uint32_t d = 0;
-    for (uint32_t i = 0; i < nc; i++) {
-        const int v = (int)pa[i] - (int)pb[i];
-        d += (uint32_t)(v * v);
+    Frame16 f;
+    int acc = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) {
+        const uint32_t lo = (2 * i < nc) ? (uint32_t)(uint16_t)p[2 * i] : 0u, hi = (2 * i + 1 < nc) ? (uint32_t)(uint16_t)p[2 * i + 1] : 0u;
+        f.w[i] = lo | (hi << 16);
+        acc = sdot2(f.w[i], f.w[i], acc);
     }
-    return cvt_u32(sqrt_rn_int((float)d));
+    f.n = (uint32_t)acc;
+    return f;
+}
+__device__ __forceinline__ uint32_t get_dis_n(const Frame16 &a, const Frame16 &b)
+{
+    int dot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) dot = sdot2(a.w[i], b.w[i], dot);
+    return cvt_u32(sqrt_rn_int((float)(a.n + b.n - 2u * (uint32_t)dot)));
 }
 __global__ void __launch_bounds__(128) k_dtw_gen(const DtwArgs a)
 {
     const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= (uint64_t)a.B * a.K) return;
-    const uint32_t b = (uint32_t)(pid / a.K), k = (uint32_t)(pid - (uint64_t)b * a.K), nc = a.n_coef;
+    // (template major, utterance minor: the lanes of a wave walk one template, so its rows are fetched once per wave)
+    const uint32_t k = (uint32_t)(pid / a.B), b = (uint32_t)(pid - (uint64_t)k * a.B), nc = a.n_coef;
     uint32_t in_n, ok;
     if (a.in_frames) {
         in_n = a.in_frames[b];
@@ -177,27 +196,39 @@ __global__ void __launch_bounds__(128) k_dtw_gen(const DtwArgs a)
         const uint32_t in_rows = a.max_frames, mdl_rows = a.tpl_rows;
         const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142
         const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
-        uint32_t px = 0, py = 0, dis = get_dis_n(in, mdl, nc), step = 1;
+        uint32_t px = 0, py = 0, step = 1;
+        Frame16 ci = load_frame_n(in, nc), cm = load_frame_n(mdl, nc);
+        uint32_t dis = get_dis_n(ci, cm);
+        // rows px+1 / py+1 are read even past the sequence end (do-while, DTW.C:150-154), clamped to the allocation
+        Frame16 ni = load_frame_n(in + (size_t)(1 < in_rows ? 1 : in_rows - 1) * nc, nc);
+        Frame16 nm = load_frame_n(mdl + (size_t)(1 < mdl_rows ? 1 : mdl_rows - 1) * nc, nc);
         do {
-            // rows px+1 / py+1 are read even past the sequence end (do-while, DTW.C:150-154), clamped to the allocation
-            const uint32_t rx = (px + 1 < in_rows) ? px + 1 : in_rows - 1, ry = (py + 1 < mdl_rows) ? py + 1 : mdl_rows - 1;
-            const int16_t *ci = in + (size_t)px * nc, *ni = in + (size_t)rx * nc, *cm = mdl + (size_t)py * nc, *nm = mdl + (size_t)ry * nc;
             const int x = (int)px + 1, y = (int)py + 1;
-            const uint32_t up = dtw_out(x, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(nm, ci, nc);
-            const uint32_t right = dtw_out(x + 1, y, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(cm, ni, nc);
-            const uint32_t diag = dtw_out(x + 1, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(nm, ni, nc);
+            const uint32_t up = dtw_out(x, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(nm, ci);
+            const uint32_t right = dtw_out(x + 1, y, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(cm, ni);
+            const uint32_t diag = dtw_out(x + 1, y + 1, X1, X2, (int)in_n, (int)mdl_n) ? SR_DIS_ERR : get_dis_n(nm, ni);
             uint32_t mn = diag;  // DTW.C:156-164
             if (mn > right) mn = right;
             if (mn > up) mn = up;
             dis += mn;
             const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
-            if (mv_diag || !mv_up) px++;
-            if (mv_diag || mv_up) py++;
+            if (mv_diag || !mv_up) {
+                px++;
+                ci = ni;
+                const uint32_t rx = (px + 1 < in_rows) ? px + 1 : in_rows - 1;
+                ni = load_frame_n(in + (size_t)rx * nc, nc);
+            }
+            if (mv_diag || mv_up) {
+                py++;
+                cm = nm;
+                const uint32_t ry = (py + 1 < mdl_rows) ? py + 1 : mdl_rows - 1;
+                nm = load_frame_n(mdl + (size_t)ry * nc, nc);
+            }
             step = (step + 1) & 0xFFFF;
         } while (px + 1 < in_n && py + 1 < mdl_n);  // DTW.C:188
         score = dis / step;
     }
-    a.scores[pid] = score;
+    a.scores[(size_t)b * a.K + k] = score;
 }
 
 // ---- k_dtw_lds: the production DTW kernel ---------------------------------------------------------

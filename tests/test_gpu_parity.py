@@ -867,6 +867,18 @@ def test_bench_other_configs_and_roofline_keys():
     assert j["roofline"]["traffic_stale"] in (True, False) and "sclk" in j
 
 
+def test_bench_scorer_dp_line():
+    """`python bench.py --scorer dp`: the opt-in full-DP scorer timed on its own (never the headline metric), one JSON line
+    with the kernel's name, pairs/s, cells/s and a parity sample against its own oracle"""
+    j, _ = _run_bench(["--scorer", "dp", "--batch", "2048", "--steps", "2"], {})
+    d = j["dp"]
+    assert "NON-REFERENCE" in j["metric"] and j["n_gpus"] == 1 and j["value"] == d["value"] > 0
+    assert d["kernel"] == "k_dtw_dp_band<8>" and d["parity_on_sample"]["identical"] is True and d["parity_on_sample"]["pairs"] == 6400
+    assert abs(d["pairs_per_s"] - 100 * d["value"]) / d["pairs_per_s"] < 1e-9
+    j, _ = _run_bench(["--scorer", "dp", "--dp-lanes", "1", "--batch", "512", "--steps", "1"], {})
+    assert j["dp"]["kernel"] == "k_dtw_dp_wave64" and j["dp"]["parity_on_sample"]["identical"] is True
+
+
 # ----------------------------------------------------------------------------- SURVEY 8(f) rows
 def test_packed12_host_transport_matches_the_u16_call(eng119, golden):
     """sr_recognize_batch_packed12: 12-bit ADC codes packed two samples in three bytes, unpacked on the device -- identical
