@@ -686,7 +686,7 @@ def run_rank(args):
 
 PMC_SOURCES = {  # the translation units (+ the device headers they include) each committed PMC file depends on
     "pmc_traffic.json": ("k_mfcc.hip", "sr_dev.h", "sr_fft_dev.h", "sr_device.h"),
-    "pmc_valu.json": ("k_vad.hip", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
+    "pmc_valu.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
     "pmc_valu_dp.json": ("k_dtw_dp.hip", "sr_dev.h", "sr_dtw_dev.h", "sr_device.h"),
 }
 

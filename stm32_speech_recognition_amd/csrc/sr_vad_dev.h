@@ -167,7 +167,9 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
                     t++;
                 }
             } else if (cur == 1) {
-                const uint32_t need = v_durmin - front;
+                // the count is checked on a LOUD frame met in this state, after front++ (VAD.C:173-181): at least one more
+                // loud frame is needed even when v_durmin is 1 (hops above 40 ms)
+                const uint32_t need = (v_durmin > front) ? v_durmin - front : 1u;
                 if (ones >= need) {
                     t += need;
                     const int i = (int)((jb + t - 1) * kHop);  // the frame that completed the run
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
                     t++;
                 }
             } else {
-                const uint32_t need = s_durmax - back;
+                const uint32_t need = (s_durmax > back) ? s_durmax - back : 1u;  // likewise (VAD.C:196-207)
                 if (zeros >= need) {
                     t += need;
                     const int i = (int)((jb + t - 1) * kHop);

@@ -78,6 +78,10 @@ GENERIC_CONFIGS = [
      dict(fs=20000, n_mel=30, n_coef=12)),
     (dict(frame_time_ms=64, frame_mov_ms=32, n_mel=64, n_coef=16, noise_len_ms=960),
      dict(frame_time=64, frame_mov_t=32, n_mel=64, n_coef=16, noise_len_t=960)),
+    # hops above 40 ms: the duration limits of VAD.C:72-75 become ONE frame (80 / 64 = 110 / 64 = 1), where the onset / tail
+    # counters are still only checked on the second frame (VAD.C:173-181, 196-207)
+    (dict(fs=4000, frame_time_ms=128, frame_mov_ms=64, n_mel=12, n_coef=6, noise_len_ms=1920),
+     dict(fs=4000, frame_time=128, frame_mov_t=64, n_mel=12, n_coef=6, noise_len_t=1920)),
 ]
 
 

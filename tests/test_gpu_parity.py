@@ -1200,6 +1200,78 @@ def test_generic_front_end_matches_oracle(ci):
     eng.close()
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_generic_front_end_random_configurations(seed):
+    """GENERIC front end, configurations drawn at random from everything sr_create accepts (sampling rate 4..48 kHz in
+    4 kHz steps x the framings that give a 160 / 240 / 256 / 320 / 400 / 512-sample frame, any even filter count 4..64, any
+    feature width 1..16, the shortest noise head that holds whole frames and whole 30 ms blocks): engine == parametrised
+    oracle on thresholds, segments, frame counts, MFCC, scores and argmin, whatever the VAD makes of the captures."""
+    from math import gcd
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(9000 + seed)
+    combos = [(fs, ft) for fs in range(4000, 48001, 4000) for ft in range(2, 130, 2)
+              if fs // 1000 * ft in (160, 240, 256, 320, 400, 512)]
+    fs, ft = combos[int(rng.integers(0, len(combos)))]
+    n_mel, n_coef = int(rng.integers(2, 33)) * 2, int(rng.integers(1, 17))
+    if (fs, ft, n_mel, n_coef) == (8000, 20, 24, 12):
+        n_mel = 26
+    noise_ms = 30 * ft // gcd(30, ft)                      # whole 30 ms blocks (VAD.C:48-63) and whole frames
+    noise_ms *= max(1, -(-240 // noise_ms))                # at least 240 ms of noise
+    ekw = dict(fs=fs, frame_time_ms=ft, frame_mov_ms=ft // 2, n_mel=n_mel, n_coef=n_coef, noise_len_ms=noise_ms)
+    okw = dict(fs=fs, frame_time=ft, frame_mov_t=ft // 2, n_mel=n_mel, n_coef=n_coef, noise_len_t=noise_ms)
+    maxf, K, B = 120, 9, 40
+    orc = ol.Oracle(max_frames=maxf, **okw)
+    eng = Engine(max_frames=maxf, device=0, **ekw)
+    fl, hop, nl = orc.frame_len, orc.hop, orc.noise_len
+    # captures: quiet head of nl samples, then bursts of a few tones with pauses, 12-bit codes
+    S = (nl + hop * 150 + fl + 7) // 8 * 8
+
+    def captures(n):
+        t = np.arange(S)[None, :]
+        f0 = rng.uniform(0.002, 0.2, (n, 1))
+        env = (np.sin(2 * np.pi * t / (hop * rng.uniform(20, 90, (n, 1))) + rng.uniform(0, 6, (n, 1))) > rng.uniform(-0.3, 0.6, (n, 1)))
+        sig = 600 * np.sin(2 * np.pi * f0 * t) * env + 250 * np.sin(2 * np.pi * 3.1 * f0 * t) * env
+        sig[:, :nl + hop * 4] = 0
+        return np.clip(2048 + sig + rng.normal(0, 7, (n, S)), 0, 4095).astype(np.uint16)
+
+    tp = captures(3 * K)
+    tm, tf = np.zeros((K, maxf + 1, n_coef), np.int16), np.zeros(K, np.uint32)
+    k = 0
+    for row in tp:
+        rc, a = orc.noise_atap(row)
+        seg = orc.vad(row, a)
+        if seg[1] < 0 or seg[0] < 1:
+            continue
+        n, m = orc.mfcc(row, seg[0], seg[1], a)
+        if n == 0:
+            continue
+        tm[k, :n], tf[k] = m, n
+        k += 1
+        if k == K:
+            break
+    if k < 2:
+        pytest.skip(f"the VAD found no usable template segment at {ekw}")
+    tm, tf = tm[:k], tf[:k]
+    pcm = captures(B)
+    pcm[3] = 2048
+    eng.set_templates_dense(tm, tf)
+    out = eng.recognize(pcm)
+    tpl = orc.make_templates(tm, tf)
+    ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
+    for b in range(B):
+        rc, a = orc.noise_atap(pcm[b])
+        seg = orc.vad(pcm[b], a)
+        v = out["vad"][b]
+        assert (v["mid_val"], v["n_thl"], v["z_thl"], v["s_thl"]) == a.astuple(), (ekw, b)
+        assert np.array_equal(v["seg"], seg), (ekw, b)
+    assert np.array_equal(out["results"]["status"], ores["status"]) and np.array_equal(out["results"]["frm_num"], ores["frm_num"]), ekw
+    assert np.array_equal(out["mfcc"], omf), ekw
+    assert np.array_equal(out["scores"], osc), ekw
+    for f in ("best_tpl", "min_dis"):
+        assert np.array_equal(out["results"][f], ores[f]), (ekw, f)
+    eng.close()
+
+
 def test_extension_front_end_matches_its_oracle():
     """EXTENSION (no reference counterpart): BASELINE configs[4] front end -- 16 kHz, 320/160 framing, 512-point
     transform (2 x ST-style 256-point radix-4 + one radix-2 pass, oracle/q15_fft.c), 40 Mel, 12 MFCC.
