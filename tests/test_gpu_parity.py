@@ -993,6 +993,36 @@ def test_dtw_dp_extension_matches_its_oracle(lanes):
     eng.close()
 
 
+@pytest.mark.parametrize("lanes,seed", [(8, 0), (8, 1), (16, 2), (4, 3)])
+def test_dtw_dp_random_lengths_match_its_oracle(lanes, seed):
+    """full-DP scorer on 200 x 48 = 9 600 pairs of random lengths (1..maxf, every gate outcome, bands of every shape: the
+    strips of a wave carry groups that start, narrow and finish at different steps), random features incl. repeated rows
+    (distance-0 plateaus), frame caps that are / are not multiples of the strip width"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(5100 + seed)
+    maxf = int(rng.choice([37, 64, 101, 130]))
+    K, B = 48, 200
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(1, maxf + 1, K).astype(np.uint32)
+    tm = rng.integers(-3000, 3000, (K, maxf + 1, 12)).astype(np.int16)
+    inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
+    im = rng.integers(-3000, 3000, (B, maxf, 12)).astype(np.int16)
+    for b in range(0, B, 7):   # plateaus: runs of identical rows, and copies of template stretches
+        im[b, 5:5 + maxf // 3] = im[b, 5]
+        k = b % K
+        n = min(int(inf[b]), int(tf[k]))
+        im[b, :n] = tm[k, :n]
+    valid = (rng.random(K) > 0.1).astype(np.uint8)
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf, valid)
+    eng.set_dp_lanes(lanes)
+    got = eng.dtw_dp(im, inf)
+    want = orc.dtw_dp_batch(im, inf, tm, np.where(valid != 0, tf, 0), n_threads=8)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    assert 0.2 < (want == ol.DIS_ERR).mean() < 0.8
+    eng.close()
+
+
 def test_dtw_dp_full_scale_store_takes_the_generic_kernel():
     """coefficients beyond +-16383 do not fit the band kernel's -2*coef rows: the store is scored by the one-wave-per-pair
     kernel, same results as the oracle (u32 wrap of the squared distance included)"""
