@@ -1299,6 +1299,27 @@ def test_generic_front_end_random_configurations(seed):
     assert np.array_equal(out["scores"], osc), ekw
     for f in ("best_tpl", "min_dis"):
         assert np.array_equal(out["results"][f], ores[f]), (ekw, f)
+    # every VAD segment matched like segment 0 (sr_recognize_segments_batch), and template training into a slot image
+    # whose records are n_coef wide (sr_train_store), on the same kernels
+    sres, ssc, svd = eng.recognize_segments(pcm[:12])
+    for b in range(12):
+        wr, ws = orc.recognize_segments(pcm[b], tpl)
+        for s_ in range(3):
+            assert (sres[s_][b]["status"], sres[s_][b]["frm_num"], sres[s_][b]["min_dis"], sres[s_][b]["best_tpl"]) == \
+                   (wr[s_]["status"], wr[s_]["frm_num"], wr[s_]["min_dis"], wr[s_]["best_tpl"]), (ekw, b, s_)
+            assert np.array_equal(ssc[s_][b], ws[s_]), (ekw, b, s_)
+    stride = 4 + 2 * n_coef * (maxf + 1)
+    store, st = eng.train_store(tp[:6], np.arange(6), n_slots=6, stride=stride)
+    for i in range(6):
+        rc, a = orc.noise_atap(tp[i])
+        seg = orc.vad(tp[i], a)
+        n, m = (0, None) if seg[1] < 0 or seg[0] < 1 else orc.mfcc(tp[i], seg[0], seg[1], a)
+        slot = store[i * stride:(i + 1) * stride]
+        if n:
+            assert st[i] == 0 and tuple(slot[:4].view(np.uint16)) == (12345, n), (ekw, i)
+            assert np.array_equal(slot[4:4 + n * n_coef * 2].view(np.int16).reshape(n, n_coef), m), (ekw, i)
+        else:
+            assert st[i] != 0 and (slot == 0xFF).all(), (ekw, i)
     eng.close()
 
 
