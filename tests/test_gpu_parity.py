@@ -1561,6 +1561,27 @@ def test_argument_checks_and_edge_sizes(golden):
     e2.close()
 
 
+def test_development_hooks_change_geometry_not_results(golden):
+    """sr_dev_hook (development knobs, read when an engine is created / a store is set): a forced frame-kernel grid, forced
+    DTW workgroup shapes (utterances x templates per workgroup, tie-table size) -- same results as the golden fixture"""
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import dev_hook
+    pcm = golden["pcm"]
+    for hooks in (dict(mfcc_grid=3), dict(dtw_u=1, dtw_kc=7), dict(dtw_u=9, dtw_tie_g=4096), dict(dtw_kc=1, dtw_debug=1)):
+        for k, v in hooks.items():
+            dev_hook(k, v)
+        try:
+            e = Engine(max_frames=119, device=0)
+            e.set_templates_store(golden["store"])
+            out = e.recognize(np.tile(pcm, (9, 1)))
+            e.close()
+        finally:
+            for k in hooks:
+                dev_hook(k, 0)
+        assert np.array_equal(out["results"]["min_dis"], np.tile(golden["recg_dis"], 9)), hooks
+        assert np.array_equal(out["scores"][:len(pcm)], golden["recg_scores"]), hooks
+
+
 def test_log_and_sqrt_device_functions_swept_directly(eng119):
     """(u32)(log(x)*100), (u32)sqrtf(x) and (u32)(sqrtf(r)*10) as the kernels compute them, against the same C
     expressions on the host: every step position of the log table +-1, perfect squares +-1 over the whole u32
