@@ -133,7 +133,8 @@ struct sr_engine {
                                            // 3 -> 28.2, 4 -> 30.0 ms per 65 536 utterances (1 -> 32.0)
     uint32_t pipe_min_chunk = 4096;        // SR_PIPE_MIN_CHUNK: utterances per chunk at least (smaller chunks lose more than they gain:
                                            // 4 096 x 10 as two chunks of 2 048: 1.93 ms per step, as one chunk 1.63)
-    uint32_t pipe_max_chunks = 12;         // SR_PIPE_MAX_CHUNKS
+    uint32_t pipe_max_chunks = 12;         // chunks per call at most (sr_set_pipeline); 6 for large stores, see upload_templates
+    bool pipe_user_set = false;            // sr_set_pipeline was called: the engine no longer adapts the chunk count to the store
     // profiling (sr_set_profiling / sr_get_stage_ms): events recorded since profiling was switched on
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // 5 per kernel group (chunk): before VAD, MFCC, DTW, argmin, after argmin
@@ -509,6 +510,10 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
                 std::fprintf(stderr, "sr_engine: k_dtw_lds geometry for K = %u, %u rows: U = %u, Kc = %u, tie table %u, LDS %zu bytes\n", K,
                              h->cfg.max_frames, h->dtw_u, kc, tie_g, lds);
     }
+    // Chunk count of the device-resident pipeline by store size (round-4 sweeps, profiles/experiments/RESULTS.md): with
+    // 100 templates 3 streams x 6..15 chunks are equivalent (22.3 ms per 65 536 utterances); with 500 templates the DTW
+    // launches dominate and fewer, longer chunks win by 1 % (3 x 6: 45.0-46.2 ms, 3 x 12: 45.2-46.7).
+    if (!h->pipe_user_set) h->pipe_max_chunks = K >= 256 ? 6 : 12;
     h->K = K;
     h->tpl_rows = rows;
     h->tpl_stride = rows * nc;
@@ -620,6 +625,7 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
     h->pipe_streams = streams;
     h->pipe_min_chunk = min_chunk;
     h->pipe_max_chunks = max_chunks;
+    h->pipe_user_set = true;
     return SR_OK;
 }
 
