@@ -52,7 +52,7 @@ extern "C" {
  *   reference   fs 8000, 20/10 ms framing (160/80 samples), nfft 1024, 24 Mel, 12 MFCC   (the firmware's constants)
  *   extension   fs 16000, 20/10 ms framing (320/160 samples), nfft 512, 40 Mel, 12 MFCC   (no reference counterpart)
  * Every other accepted configuration runs the GENERIC front end (same arithmetic rules, tables from the same formulas, about
- * 4x slower per frame; no reference counterpart for the constants):
+ * 2.3x slower per frame; no reference counterpart for the constants):
  *   nfft 1024; fs a multiple of 4000 Hz; frame_time_ms = 2 * frame_mov_ms with a frame of 160, 240, 256, 320, 400 or 512
  *   samples; n_mel even, 4..64; n_coef 1..16 (feature records are n_coef wide everywhere: mfcc[B][max_frames][n_coef],
  *   template rows, slot images; sr_get_mdl_batch and the full-DP scorer require 12).
