@@ -1285,6 +1285,8 @@ def test_generic_front_end_random_configurations(seed):
     pcm = captures(B)
     pcm[3] = 2048
     eng.set_templates_dense(tm, tf)
+    if seed & 1:  # the chunked multi-stream pipeline with ragged chunks, feature records n_coef wide
+        eng.set_pipeline(streams=3, min_chunk=7, max_chunks=12)
     out = eng.recognize(pcm)
     tpl = orc.make_templates(tm, tf)
     ores, omf, osc = orc.recognize_batch(pcm, tpl, n_threads=8)
