@@ -128,7 +128,7 @@ uint32_t mfcc_frames_per_tile(uint32_t frame_len);      // frames one work item 
 uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on the current device
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 // utterances per k_dtw_lds workgroup for K templates / max_frames rows (0 = use the generic kernel); tuning
-// override: environment variable SR_DTW_U, read when the template store is set
+// override: development hooks dtw_u / dtw_kc / dtw_tie_g (sr_dev_hook), read when the template store is set
 uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g, uint32_t *kc);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer

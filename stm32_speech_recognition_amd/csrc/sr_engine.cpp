@@ -129,9 +129,9 @@ struct sr_engine {
     static constexpr uint32_t kPipeStreams = 4;
     hipStream_t st_pipe[kPipeStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kPipeStreams] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t pipe_streams = 3;             // SR_PIPE_STREAMS (1 = one chunk on the caller's stream); measured: 2 -> 28.8,
+    uint32_t pipe_streams = 3;             // sr_set_pipeline streams (1 = one chunk on the caller's stream); measured: 2 -> 28.8,
                                            // 3 -> 28.2, 4 -> 30.0 ms per 65 536 utterances (1 -> 32.0)
-    uint32_t pipe_min_chunk = 4096;        // SR_PIPE_MIN_CHUNK: utterances per chunk at least (smaller chunks lose more than they gain:
+    uint32_t pipe_min_chunk = 4096;        // sr_set_pipeline min_chunk: utterances per chunk at least (smaller chunks lose more than they gain:
                                            // 4 096 x 10 as two chunks of 2 048: 1.93 ms per step, as one chunk 1.63)
     uint32_t pipe_max_chunks = 12;         // chunks per call at most (sr_set_pipeline); 6 for large stores, see upload_templates
     bool pipe_user_set = false;            // sr_set_pipeline was called: the engine no longer adapts the chunk count to the store
