@@ -520,6 +520,13 @@ void sr_oracle_math_diag_mt(const uint32_t *in, uint32_t *out, uint32_t n, uint3
     for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
 }
 
+/* dtw_limit (DTW.C:76-109) for one point of one length pair: 1 = outside the parallelogram (test helper) */
+int sr_oracle_dtw_outside(int x, int y, uint32_t in_n, uint32_t mdl_n)
+{
+    int X1 = (int)(uint16_t)((2 * (int)mdl_n - (int)in_n) / 3), X2 = (int)(uint16_t)((4 * (int)in_n - 2 * (int)mdl_n) / 3);
+    return dtw_outside(x, y, X1, X2, (int)in_n, (int)mdl_n);
+}
+
 /* ---- NON-REFERENCE extension: full dynamic-programming DTW ---------------
  * Own definition (no reference counterpart; the reference's dtw() is the greedy walk above):
  *   cells (x,y), 1-based, allowed iff dtw_limit(x,y) == ins (DTW.C:76-109) with the pair's X1/X2;

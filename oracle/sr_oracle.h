@@ -96,6 +96,8 @@ void sr_oracle_math_diag(const uint32_t *in, uint32_t *out, uint32_t n);
 /* NON-REFERENCE extension (own definition, see sr_oracle.c): full-DP DTW with the same parallelogram and distance. */
 uint32_t sr_oracle_dtw_dp(const int16_t *in, uint32_t in_frames, const int16_t *mdl, uint32_t mdl_frames,
                           uint32_t n_coef);
+/* dtw_limit (DTW.C:76-109) for one point of one length pair: 1 = outside (test helper) */
+int sr_oracle_dtw_outside(int x, int y, uint32_t in_frames, uint32_t mdl_frames);
 /* all B x K pairs, threaded (test helper); mdl_n[k] == 0 marks an invalid slot */
 void sr_oracle_dtw_dp_batch(const int16_t *in, const uint32_t *in_n, uint32_t in_rows, uint32_t B, const int16_t *mdl,
                             const uint32_t *mdl_n, uint32_t mdl_rows, uint32_t K, uint32_t nc, uint32_t *out,

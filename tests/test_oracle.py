@@ -126,6 +126,34 @@ def test_generic_front_end_tables_and_config_gate():
             engine.build_tables(**bad)
 
 
+def test_dtw_limit_interval_form_used_by_the_dp_kernel_and_bench(oracle):
+    """The full-DP kernel (and bench.py's cell count) evaluates dtw_limit (DTW.C:76-109) once per column as an interval
+    lb(x) <= y <= ub(x): ub = x < X1 ? 2x+1 : ((x + 5 - in + 2 mdl) >> 1) - 1, lb = x < X2 ? x >> 1 : 2x + mdl - 2 in - 3.
+    Checked point by point against the oracle's dtw_limit for every length pair up to 70 x 70 that passes the gate, and
+    bench.dp_cells_per_pair against the same count."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    L = oracle.L
+    n_pairs = 0
+    for in_n in range(1, 71):
+        for mdl_n in range(1, 71):
+            if in_n > 2 * mdl_n or 2 * in_n < mdl_n:
+                continue
+            X1, X2 = int((2 * mdl_n - in_n) / 3) & 0xFFFF, int((4 * in_n - 2 * mdl_n) / 3) & 0xFFFF
+            cells = 0
+            for x in range(1, in_n + 1):
+                ub = 2 * x + 1 if x < X1 else ((x + 5 - in_n + 2 * mdl_n) >> 1) - 1
+                lb = (x >> 1) if x < X2 else 2 * x + mdl_n - 2 * in_n - 3
+                for y in range(1, mdl_n + 1):
+                    assert (lb <= y <= ub) == (L.sr_oracle_dtw_outside(x, y, in_n, mdl_n) == 0), (in_n, mdl_n, x, y)
+                cells += max(0, min(ub, mdl_n) - max(lb, 1) + 1)
+            got, ok = bench.dp_cells_per_pair(in_n, [mdl_n])
+            assert ok == 1 and got == cells, (in_n, mdl_n, got, cells)
+            n_pairs += 1
+    assert n_pairs > 2000
+
+
 def test_preemphasis_float_form_is_exact():
     """MFCC.C:119 multiplies the previous sample by hp_ratio = 95/100 in integer arithmetic (p*95/100, truncated toward
     zero).  The frame kernels evaluate it as (int)((float)p * 0.95000005f) -- convert, IEEE multiply, truncating convert --
