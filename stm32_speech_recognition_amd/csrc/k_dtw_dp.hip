@@ -338,9 +338,15 @@ static int dp_waves_for(int G) { (void)G; return 4; }
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s)
 {
     if (!a.B || !a.K) return;
-    int G = (int)a.dp_lanes;  // 0 = default
-    if (G != 1 && G != 4 && G != 8 && G != 16) G = 8;
+    int G = (int)a.dp_lanes;  // 0 = choose
     uint32_t rp = 0;
+    if (G != 1 && G != 4 && G != 8 && G != 16) {
+        // 8 lanes per pair while three of its workgroups fit a CU's 160 KiB (handed out in granules of 1280 bytes): 111 ms
+        // per 65 536 x 100 pairs at a 320-frame cap; one granule more and only two fit (153 ms) -- then 16 lanes per pair
+        // (half the boundary columns, 120 ms with three or four workgroups per CU) is the better shape
+        auto wgs = [&](int g) { return (160u * 1024u) / ((dp_band_lds(a.tpl_rows, g, dp_waves_for(g), nullptr) + 1279u) / 1280u * 1280u); };
+        G = (wgs(8) >= 3 || wgs(16) < 3) ? 8 : 16;
+    }
     if (G != 1 && (!a.tplR || dp_band_lds(a.tpl_rows, G, dp_waves_for(G), &rp) > 150u * 1024u)) {
         G = 16;  // fewer pairs per wave: fewer boundary columns
         if (!a.tplR || dp_band_lds(a.tpl_rows, G, dp_waves_for(G), &rp) > 150u * 1024u) G = 1;
