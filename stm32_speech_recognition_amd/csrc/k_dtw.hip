@@ -328,10 +328,28 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         const uint32_t n = s_n[u];
         if (!n) continue;
         const uint32_t rows = (n + 1 < R) ? n + 1 : R;
+        const uint32_t nc = a.d.n_coef;  // 12, or fewer on the GENERIC front end: the LDS image is zero-padded to 12
         const uint2 *src = (const uint2 *)(a.d.mfcc + (size_t)(b0 + u) * R * kCoef);
         u32x2 *dst = s_rows + (size_t)u * (row_stride / 2);
         for (uint32_t r = tid; r < rows; r += blockDim.x) {
-            const uint2 q0 = src[3 * r], q1 = src[3 * r + 1], q2 = src[3 * r + 2];
+            uint2 q0, q1, q2;
+            if (nc == (uint32_t)kCoef) {
+                q0 = src[3 * r];
+                q1 = src[3 * r + 1];
+                q2 = src[3 * r + 2];
+            } else {  // narrower rows (2-byte aligned when nc is odd): coefficient by coefficient; zero padding adds nothing
+                      // to get_dis' sum of squares (DTW.C:45-62)
+                const int16_t *p = a.d.mfcc + ((size_t)(b0 + u) * R + r) * nc;
+                uint32_t w[6];
+#pragma unroll
+                for (uint32_t i = 0; i < 6; i++) {
+                    const uint32_t lo = (2 * i < nc) ? (uint32_t)(uint16_t)p[2 * i] : 0u, hi = (2 * i + 1 < nc) ? (uint32_t)(uint16_t)p[2 * i + 1] : 0u;
+                    w[i] = lo | (hi << 16);
+                }
+                q0 = make_uint2(w[0], w[1]);
+                q1 = make_uint2(w[2], w[3]);
+                q2 = make_uint2(w[4], w[5]);
+            }
             int nr = sdot2z(q0.x, q0.x);
             nr = sdot2(q0.y, q0.y, nr);
             nr = sdot2(q1.x, q1.x, nr);
@@ -614,11 +632,13 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
     const uint64_t n = (uint64_t)a.B * a.K;
     if (!n) return;
     // U (utterances per workgroup) and the LDS size were chosen once, when the template store was set
-    if (a.n_coef != kCoef) {  // GENERIC front end with another feature width
+    const uint32_t U = a.tplR ? a.lds_u : 0;
+    // GENERIC front end with another feature width: up to 12 coefficients ride the staged kernel (rows zero-padded to 12 in
+    // its LDS image and in the length-sorted store); wider rows, or narrower ones whose store cannot be staged, take k_dtw_gen
+    if (a.n_coef > (uint32_t)kCoef || (a.n_coef < (uint32_t)kCoef && !U)) {
         hipLaunchKernelGGL(k_dtw_gen, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
         return;
     }
-    const uint32_t U = a.tplR ? a.lds_u : 0;
     const size_t lds = a.lds_bytes;
     if (U) {
         const uint32_t Kc = (a.lds_kc && a.lds_kc < a.K) ? a.lds_kc : a.K, chunks = (a.K + Kc - 1) / Kc;

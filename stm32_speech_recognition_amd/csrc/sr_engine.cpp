@@ -449,12 +449,14 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
         // (unreachable for log-Mel cepstra, reachable for arbitrary s16 records) disable the staged kernel for
         // this store and the generic k_dtw, which makes no such assumption, scores it.
         std::vector<uint32_t> rt((size_t)rows * K * 8, 0u), fs(K);
-        if (nc != (uint32_t)kCoef) fits = false;  // another feature width: the generic kernel scores the store
+        if (nc > (uint32_t)kCoef) fits = false;  // wider feature rows: the generic kernel scores the store
         for (uint32_t ks = 0; ks < K; ks++) {
             const uint32_t k = order[ks];
             fs[ks] = v[k] ? f[k] : 0u;
-            for (uint32_t r = 0; r < rows && nc == (uint32_t)kCoef; r++) {
-                const int16_t *src = &m[((size_t)k * rows + r) * kCoef];
+            for (uint32_t r = 0; r < rows && nc <= (uint32_t)kCoef; r++) {
+                // narrower rows (GENERIC front end, n_coef < 12) are zero-padded to 12: nothing is added to get_dis' sum
+                int16_t src[kCoef] = {0};
+                std::memcpy(src, &m[((size_t)k * rows + r) * nc], (size_t)nc * 2);
                 uint32_t *dst = &rt[((size_t)r * K + ks) * 8];
                 int16_t neg2[kCoef];
                 uint32_t nrm = 0;
