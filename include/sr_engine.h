@@ -222,9 +222,10 @@ int sr_get_mdl_batch(sr_engine *h, const int16_t *in1, const uint32_t *n1, uint3
  * The reference's dtw() is a greedy walk (DTW.C:150-188), so these scores differ from dtw()'s by design and are
  * never used by sr_recognize_* or the dtw symbol. */
 /* Kernel: a band-limited anti-diagonal wavefront, `lanes` lanes of a wave per (utterance, template) pair (strips of that
- * many utterance frames; the value from the left moves by DPP, strip boundaries through LDS, the template staged in LDS);
- * sr_set_dp_lanes chooses 4, 8 or 16 (0 = automatic: 8 while three of its workgroups fit a CU's LDS, else 16), or 1 = the first version (one wave per pair, 64-column sweeps of the
- * whole rectangle), which also serves stores the band kernel cannot stage.  All variants give identical scores. */
+ * many utterance frames; the value from the left moves by DPP, strip boundaries through LDS, the template staged in
+ * LDS); sr_set_dp_lanes chooses 4, 8 or 16 (0 = automatic: 8 while three of its workgroups fit a CU's LDS, else 16),
+ * or 1 = the first version (one wave per pair, 64-column sweeps of the whole rectangle), which also serves stores the
+ * band kernel cannot stage.  All variants give identical scores. */
 int sr_set_dp_lanes(sr_engine *h, uint32_t lanes);
 int sr_dtw_dp_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames, uint32_t B, uint32_t *scores);
 int sr_dtw_dp_batch_dev(sr_engine *h, const int16_t *d_mfcc, const uint32_t *d_in_frames, const sr_vad_rec *d_vad,
