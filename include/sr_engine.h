@@ -280,6 +280,13 @@ int sr_allgather_scores(void *nccl_comm, const uint32_t *d_scores, uint32_t *d_a
  * overlap with the other chunks' kernels), ms[4] = one whole call on the caller's stream (fork -> join).
  * sr_get_stage_launches: launches of each kernel per call (= chunks). */
 int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t max_chunks); /* same knobs at run time */
+/* Small launches -- one capture against the store (spch_recg, main.c:276-295), one dtw() call, a handful of captures -- are
+ * latency-bound: dtw (DTW.C:120-192) is a serial walk, and a few hundred walks leave the GPU idle.  Up to 1024 pairs per
+ * launch the engine therefore scores every pair with its own workgroup (k_dtw_cells: all points of the in x mdl rectangle
+ * evaluated at once, then one lane follows the precomputed moves), provided the rectangle fits a workgroup's LDS
+ * (max_frames x longest template <= ~36 000 points; the firmware's 119 x 119 does).  Same scores bit for bit.
+ * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = whenever the rectangle fits, whatever the launch size. */
+int sr_set_small_launch(sr_engine *h, int mode);
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
 int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);

@@ -9,17 +9,21 @@ namespace sr {
 // k_mfcc
 // ------------------------------------------------------------------------------------------------
 constexpr int kMfccWaves = 4;       // waves per workgroup
-constexpr int kFramesPerWave = 16;   // consecutive frames one wave turns into MFCCs per work item
-constexpr int kFramesPerTile = kMfccWaves * kFramesPerWave;
+// consecutive frames one wave turns into MFCCs per work item: 16 in the batch form (the lane constants and tables a workgroup
+// sets up are amortised over 64 frames), 2 in the small-launch form (one capture = 110 frames is 14 workgroups instead of 2:
+// a wave's frames are a serial chain of ~1.5 us each, and with a handful of captures nothing else fills the chip)
+constexpr int kFramesPerWave = 16, kFramesPerWaveSmall = 2;
 // per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
 // rows of the filterbank outputs and of the DCT tables are kMelPad = 25 words apart: in the DCT the lanes of a wave read
 // 6 different frames x 12 different coefficients rows at the same column, and a stride of 24 folds those onto 4 banks
 constexpr int kMelPad = kMel + 1;
-constexpr int kWaveLdsWords = kXchgWords + kFramesPerWave * kMelPad + 64;  // the windowed frame aliases the exchange area;
-                                                                        // the last 64 words hold the odd filters' lane offsets
+// the windowed frame aliases the exchange area; the last 64 words hold the odd filters' lane offsets
+constexpr int mfcc_wave_lds_words(int fpw) { return kXchgWords + fpw * kMelPad + 64; }
 
+template <int kFPW>
 __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 {
+    constexpr int kWaveLdsWords = mfcc_wave_lds_words(kFPW);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_dctM[kCoef * kMelPad];
     __shared__ int s_dctS[kCoef * kMelPad];  // 32-bit: read with the wide LDS loads, no byte extraction
@@ -27,7 +31,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
     uint16_t *xw = (uint16_t *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
-    uint32_t *powb = buf + kXchgWords, *moff = powb + kFramesPerWave * kMelPad;
+    uint32_t *powb = buf + kXchgWords, *moff = powb + kFPW * kMelPad;
 
     // DCT term (MFCC.C:179): (s32)pow * dct / 100, truncated toward zero, with 0 <= pow <= 2218 (= (u32)(ln(2^32)*100))
     // and |dct| <= 128.  floor(pow*|c|/100) == (pow * M_c) >> 18 with M_c = ceil(|c| * 2^18 / 100) for every such pair
@@ -90,9 +94,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         }
         const uint16_t *row = a.pcm + (uint64_t)b * a.pcm_stride;
         int16_t *out = a.mfcc + (uint64_t)b * a.max_frames * kCoef;
-        const uint32_t f0 = tile * kFramesPerTile + w * kFramesPerWave;
+        const uint32_t f0 = tile * (kMfccWaves * kFPW) + w * kFPW;
         uint32_t nf = 0;  // frames this wave really has
-        if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFramesPerWave) ? nfrm - f0 : (uint32_t)kFramesPerWave;
+        if (f0 < nfrm) nf = (nfrm - f0 < (uint32_t)kFPW) ? nfrm - f0 : (uint32_t)kFPW;
 
         // samples of frame fi+1 are requested while frame fi is transformed
         // one 2-byte-aligned dword per sample: x[i-1] in the low half, x[i] in the high half
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         {
             int16_t *out_w = out + (size_t)f0 * kCoef;
 #pragma unroll
-            for (uint32_t t = lane; t < (uint32_t)(kFramesPerWave * kCoef); t += 64) {
+            for (uint32_t t = lane; t < (uint32_t)(kFPW * kCoef); t += 64) {
                 if (t < nf * kCoef) {
                     const uint32_t fi = umul24(t, 10923u) >> 17, h = t - umul24(fi, (uint32_t)kCoef);
                     const uint32_t *pw = powb + umul24(fi, (uint32_t)kMelPad), *dm = s_dctM + umul24(h, (uint32_t)kMelPad);
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         wave_sync();
         // rows >= frm_num of this tile are zeroed so that every row of the output is defined
         {
-            const uint32_t r0 = f0 + nf, r1 = (f0 + kFramesPerWave < a.max_frames) ? f0 + kFramesPerWave : a.max_frames;
+            const uint32_t r0 = f0 + nf, r1 = (f0 + kFPW < a.max_frames) ? f0 + kFPW : a.max_frames;
             for (uint32_t t = r0 * kCoef + lane; t < r1 * kCoef && r0 < r1; t += 64) out[t] = 0;
         }
     }
@@ -225,7 +229,9 @@ uint32_t mfcc_ext_frames_per_tile();
 int mfcc_ext_occupancy(int *per_cu);
 void launch_mfcc_ext(const MfccArgs &a, uint32_t grid, hipStream_t s);
 
-uint32_t mfcc_frames_per_tile(uint32_t frame_len) { return frame_len == 320 ? mfcc_ext_frames_per_tile() : (uint32_t)kFramesPerTile; }
+uint32_t mfcc_frames_per_tile(uint32_t frame_len) { return frame_len == 320 ? mfcc_ext_frames_per_tile() : (uint32_t)(kMfccWaves * kFramesPerWave); }
+// frames per work item of the small-launch form (the extension kernel has one form)
+uint32_t mfcc_frames_per_tile_small(uint32_t frame_len) { return frame_len == 320 ? mfcc_ext_frames_per_tile() : (uint32_t)(kMfccWaves * kFramesPerWaveSmall); }
 
 // workgroups of the frame kernel that fit on the current device at once (occupancy query x CU count)
 uint32_t mfcc_resident_workgroups(uint32_t frame_len)
@@ -237,8 +243,8 @@ uint32_t mfcc_resident_workgroups(uint32_t frame_len)
     if (frame_len == 320)
         e = mfcc_ext_occupancy(&per_cu);
     else
-        e = (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc, 64 * kMfccWaves,
-                                                              (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t));
+        e = (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mfcc<kFramesPerWave>, 64 * kMfccWaves,
+                                                              (size_t)kMfccWaves * mfcc_wave_lds_words(kFramesPerWave) * sizeof(uint32_t));
     if (e != (int)hipSuccess || per_cu < 1) return 0;
     return (uint32_t)(per_cu * n_cu);
 }
@@ -257,8 +263,13 @@ void launch_mfcc(const MfccArgs &a, hipStream_t s)
         launch_mfcc_ext(a, grid, s);
         return;
     }
-    const size_t lds = (size_t)kMfccWaves * kWaveLdsWords * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_mfcc, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
+    if (a.small_tiles) {  // a.tiles counts tiles of mfcc_frames_per_tile_small frames
+        const size_t lds = (size_t)kMfccWaves * mfcc_wave_lds_words(kFramesPerWaveSmall) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_mfcc<kFramesPerWaveSmall>, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
+        return;
+    }
+    const size_t lds = (size_t)kMfccWaves * mfcc_wave_lds_words(kFramesPerWave) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_mfcc<kFramesPerWave>, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
 }
 
 }  // namespace sr

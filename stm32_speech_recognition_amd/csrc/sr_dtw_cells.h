@@ -1,0 +1,14 @@
+// sr_dtw_cells.h -- the small-launch DTW kernel (k_dtw_cells.hip): one workgroup per (utterance, template) pair.
+#pragma once
+#include "sr_device.h"
+
+namespace sr {
+
+// the pair's rows and one word per point of the in x mdl rectangle fit one workgroup's LDS (and the store has the slack rows
+// the reference's do-while reads)
+bool dtw_cells_fits(const DtwArgs &a);
+size_t dtw_cells_lds(uint32_t max_frames, uint32_t tpl_rows);
+// scores[b][k] for every pair, identical to launch_dtw's; meant for launches of a few hundred pairs
+void launch_dtw_cells(const DtwArgs &a, hipStream_t s);
+
+}  // namespace sr

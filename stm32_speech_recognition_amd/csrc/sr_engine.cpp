@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "sr_device.h"
+#include "sr_dtw_cells.h"
 #include "sr_tables.h"
 
 namespace sr {
@@ -92,7 +93,7 @@ struct sr_engine {
     sr_config cfg;
     int device = 0;
     uint32_t noise_len = 0, atap_frm = 0;
-    uint32_t mfcc_tile = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item, resident workgroups
+    uint32_t mfcc_tile = 64, mfcc_tile_small = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item (batch / small-launch form), resident workgroups
     uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension, or the generic front end's framing
     uint32_t nc = 12, n_mel = 24;                // s16 per feature row (n_coef), Mel filters
     bool generic = false;                        // GENERIC front end (k_mfcc_gen / k_dtw_gen when nc != 12)
@@ -110,6 +111,7 @@ struct sr_engine {
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
     uint32_t dtw_u = 0, dtw_lds = 0, dtw_tie_g = 0, dtw_kc = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
     uint32_t dp_lanes = 0;         // sr_set_dp_lanes: lanes per pair of the opt-in full-DP scorer (0 = default)
+    int small_launch = 0;          // sr_set_small_launch: 0 = k_dtw_cells for launches of a few hundred pairs, 1 = never, 2 = whenever it fits
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
     DevBuf<uint8_t> s_pack;   // sr_recognize_batch_packed12: the packed rows as uploaded, before k_unpack12
@@ -313,6 +315,7 @@ int sr_create(const sr_config *cfg, sr_engine **out)
         return fail(SR_ERR_BAD_CONFIG, "frame_time_ms - frame_mov_ms must not exceed 80 ms (VAD.C:72-75)");
     }
     h->mfcc_tile = h->generic ? 1u : mfcc_frames_per_tile(h->frame_len);
+    h->mfcc_tile_small = h->generic ? 1u : mfcc_frames_per_tile_small(h->frame_len);
     // Grid of the frame kernel: FOUR times the workgroups that are resident at once, work items strided.  Exactly the
     // resident set (one persistent wave of workgroups) left ~15 % of the kernel's own time to stragglers: the workgroups
     // do not finish together, and with more, shorter ones the dispatcher back-fills the CUs that are done (measured alone
@@ -639,6 +642,14 @@ int sr_set_dp_lanes(sr_engine *h, uint32_t lanes)
     return SR_OK;
 }
 
+int sr_set_small_launch(sr_engine *h, int mode)
+{
+    if (!h) return fail(SR_ERR_BAD_ARG, "null engine");
+    if (mode < 0 || mode > 2) return fail(SR_ERR_BAD_ARG, "small-launch mode: 0 (automatic), 1 (never), 2 (whenever the store fits)");
+    h->small_launch = mode;
+    return SR_OK;
+}
+
 int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call)
 {
     if (!h || !launches_per_call) return fail(SR_ERR_BAD_ARG, "null argument");
@@ -697,6 +708,13 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.vad = d_vad;
     a.mfcc = d_mfcc;
     a.tiles = (h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile;
+    a.small_tiles = 0;
+    // Fewer work items than CUs (a handful of captures: spch_recg, get_mfcc): the frame kernel's small-launch form, 8 frames per
+    // workgroup instead of 64 -- a wave's frames are a serial chain, and nothing else would fill the chip.  Same arithmetic.
+    if (h->small_launch != 1 && h->mfcc_tile_small < h->mfcc_tile && (uint64_t)B * a.tiles < 256) {
+        a.tiles = (h->cfg.max_frames + h->mfcc_tile_small - 1) / h->mfcc_tile_small;
+        a.small_tiles = 1;
+    }
     a.grid_cap = h->mfcc_grid_cap;
     a.frame_len = h->frame_len;
     a.n_items = B * a.tiles;
@@ -750,6 +768,26 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     return a;
 }
 
+// dtw for every pair of the launch: the batch kernels (k_dtw_lds / k_dtw_gen / k_dtw), or -- a few hundred pairs, i.e. a GPU
+// that would otherwise idle behind a handful of serial walks -- one workgroup per pair (k_dtw_cells).  Same scores.
+// Measured on 110-frame captures against 80 slots of up to 119 frames (66 KB of LDS per pair, two workgroups per CU;
+// profiles/experiments/RESULTS.md): DTW of 80 / 320 / 640 / 960 / 1 280 / 1 920 pairs 33 / 42 / 61 / 73 / 90 / 127 us per
+// pair-workgroup launch against 125-135 us for the batch kernel at any of these sizes.  The automatic mode stays at two
+// rounds of resident workgroups: 512 pairs per workgroup that fits a CU's LDS (at most 4 counted).
+static uint64_t small_launch_pairs(const DtwArgs &a)
+{
+    const size_t lds = (dtw_cells_lds(a.max_frames, a.tpl_rows) + 1279) / 1280 * 1280;  // LDS granule of gfx950
+    const uint64_t per_cu = std::min<uint64_t>(4, std::max<uint64_t>(1, 160 * 1024 / lds));
+    return 512 * per_cu;
+}
+static void launch_dtw_auto(const sr_engine *h, const DtwArgs &a, hipStream_t s)
+{
+    if (h->small_launch != 1 && dtw_cells_fits(a) && (h->small_launch == 2 || (uint64_t)a.B * a.K <= small_launch_pairs(a)))
+        launch_dtw_cells(a, s);
+    else
+        launch_dtw(a, s);
+}
+
 int sr_dtw_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_vad, uint32_t B, uint32_t *d_scores,
                      sr_result *d_results, void *stream)
 {
@@ -757,7 +795,7 @@ int sr_dtw_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_va
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
     ENTER_DEVICE(h);
     DtwArgs a = dtw_args(h, d_mfcc, d_vad, nullptr, B, d_scores, d_results);
-    launch_dtw(a, (hipStream_t)stream);
+    launch_dtw_auto(h, a, (hipStream_t)stream);
     if (d_results) launch_argmin(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SR_OK;
@@ -829,7 +867,7 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
         launch_mfcc(mfcc_args(h, pc, pcm_stride, n, vc, mc), sc);
         if (prof) HIP_TRY(hipEventRecord(ev[2], sc));
         DtwArgs da = dtw_args(h, mc, vc, nullptr, n, d_scores + (size_t)b0 * h->K, d_results + b0);
-        launch_dtw(da, sc);
+        launch_dtw_auto(h, da, sc);
         if (prof) HIP_TRY(hipEventRecord(ev[3], sc));
         launch_argmin(da, sc);
         if (prof) HIP_TRY(hipEventRecord(ev[4], sc));
@@ -880,7 +918,7 @@ int sr_recognize_segments_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_
         launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, h->s_vad2.p, h->s_mfcc.p), s);
         DtwArgs da = dtw_args(h, h->s_mfcc.p, h->s_vad2.p, nullptr, B, d_scores + (size_t)sg * B * h->K,
                               d_results + (size_t)sg * B);
-        launch_dtw(da, s);
+        launch_dtw_auto(h, da, s);
         launch_argmin(da, s);
     }
     HIP_TRY(hipGetLastError());
@@ -1166,7 +1204,7 @@ int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames
     HIP_TRY(hipMemcpy(h->s_mfcc.p, in_mfcc, msz * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->s_u32a.p, in_frames, (size_t)B * 4, hipMemcpyHostToDevice));
     DtwArgs a = dtw_args(h, h->s_mfcc.p, nullptr, h->s_u32a.p, B, h->s_scores.p, h->s_results.p);
-    launch_dtw(a, nullptr);
+    launch_dtw_auto(h, a, nullptr);
     launch_argmin(a, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));

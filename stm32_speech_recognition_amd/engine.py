@@ -281,6 +281,11 @@ class Engine:
         """lanes per pair of the opt-in full-DP scorer: 0 default (8), 4 / 8 / 16 band kernel, 1 = one wave per pair"""
         self._check(self.L.sr_set_dp_lanes(self.h, C.c_uint32(lanes)))
 
+    def set_small_launch(self, mode=0):
+        """DTW of launches with few pairs: 0 automatic (one workgroup per pair up to 1024 pairs), 1 never, 2 whenever the
+        in x mdl rectangle fits a workgroup's LDS.  Same scores in every mode."""
+        self._check(self.L.sr_set_small_launch(self.h, C.c_int(mode)))
+
     def dtw_dp_dev(self, mfcc, scores, in_frames=None, vad=None, stream=None):
         """OPT-IN non-reference scorer on device tensors: mfcc int16 [B, max_frames, 12], frame counts from in_frames
         (int32 [B]) or vad records; scores int32 [B, K].  Asynchronous on `stream`."""

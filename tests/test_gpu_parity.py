@@ -35,6 +35,19 @@ def oracle():
     return ol.Oracle(max_frames=119)
 
 
+def _dtw_all_modes(eng, im, inf):
+    """sr_dtw_batch with the batch kernels (small-launch mode 1), with one workgroup per pair wherever the rectangle fits
+    (mode 2, k_dtw_cells) and in the automatic mode: scores and results must be the same bytes; returns the first"""
+    eng.set_small_launch(1)
+    sc, res = eng.dtw(im, inf)
+    for mode in (2, 0):
+        eng.set_small_launch(mode)
+        sc2, res2 = eng.dtw(im, inf)
+        assert np.array_equal(sc, sc2), mode
+        assert res.tobytes() == res2.tobytes(), mode
+    return sc, res
+
+
 def test_library_loaded_is_in_tree():
     from stm32_speech_recognition_amd import engine
     engine.load_library()
@@ -86,7 +99,7 @@ def test_dtw_matches_golden(golden):
     # all models as one store, all inputs as one batch: score[p, p] is the pair's distance
     P = len(dd)
     e.set_templates_dense(np.concatenate([db, np.zeros((P, 1, 12), np.int16)], 1), ln[:, 1])
-    sc, _ = e.dtw(da, ln[:, 0])
+    sc, _ = _dtw_all_modes(e, da, ln[:, 0])
     assert np.array_equal(np.diagonal(sc), dd)
     e.close()
 
@@ -348,6 +361,13 @@ def test_random_shapes_match_oracle(seed, maxf, K):
     assert np.array_equal(out["scores"].cpu().numpy().view(np.uint32), osc), (maxf, K, B)
     for f in ("best_tpl", "min_dis", "frm_num", "status"):
         assert np.array_equal(res[f], ores[f]), (f, maxf, K, B)
+    # the same call with one workgroup per pair (k_dtw_cells) wherever the in x mdl rectangle fits, and with it switched off
+    for mode in (2, 1):
+        eng.set_small_launch(mode)
+        out2 = eng.recognize_dev(d_pcm, eng.alloc_outputs(B, "cuda:0"))
+        torch.cuda.synchronize()
+        assert np.array_equal(out2["scores"].cpu().numpy().view(np.uint32), osc), (mode, maxf, K, B)
+        assert torch.equal(out2["results"], out["results"]), (mode, maxf, K, B)
     eng.close()
 
 
@@ -427,7 +447,7 @@ def test_dtw_stress_matches_oracle(tpl_lo, tpl_hi):
     im[::4] = rng.integers(-32768, 32767, (len(im[::4]), maxf, 12))
     eng = Engine(max_frames=maxf, device=0)
     eng.set_templates_dense(tm, tf)
-    sc, res = eng.dtw(im, inf)
+    sc, res = _dtw_all_modes(eng, im, inf)
     pad = np.zeros((1, 12), np.int16)
     want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
                     dtype=np.uint32)
@@ -457,7 +477,7 @@ def test_dtw_ties_and_perfect_squares_match_oracle():
     im[1::5, :, 0] *= 4097
     eng = Engine(max_frames=maxf, device=0)
     eng.set_templates_dense(tm, tf)
-    sc, res = eng.dtw(im, inf)
+    sc, res = _dtw_all_modes(eng, im, inf)
     pad = np.zeros((1, 12), np.int16)
     want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
                     dtype=np.uint32)
@@ -489,13 +509,47 @@ def test_dtw_near_ties_at_large_roots_match_oracle(scale):
     tm, im = tm.astype(np.int16), im.astype(np.int16)
     eng = Engine(max_frames=maxf, device=0)
     eng.set_templates_dense(tm, tf)
-    sc, res = eng.dtw(im, inf)
+    sc, res = _dtw_all_modes(eng, im, inf)
     pad = np.zeros((1, 12), np.int16)
     want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
                     dtype=np.uint32)
     assert np.array_equal(sc, want)
     ok = want != ol.DIS_ERR
     assert ok.sum() > 500 and np.median(want[ok]) > 1.5 * scale
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_small_launch_dtw_matches_oracle(seed):
+    """launches of a few pairs -- spch_recg's one capture against the store (main.c:276-295), single dtw() calls -- are scored by
+    k_dtw_cells, one workgroup per pair: every point's candidates / minimum / move first, then one lane follows the moves.
+    Random shapes around the corners of DTW.C:120-192: 1- and 2-frame sequences (the do-while reads the slack row), every
+    length gate, erased slots, inputs at the frame cap, ties (small coefficients) and full-scale rows; automatic mode with
+    B * K <= 1024, checked against the oracle and against the batch kernels"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(700 + seed)
+    maxf = int(rng.choice([2, 3, 17, 60, 119, 150]))
+    K = int(rng.choice([1, 2, 9, 80]))
+    B = int(rng.integers(1, max(2, 1024 // K // 4)))
+    orc = ol.Oracle(max_frames=maxf)
+    tf = rng.integers(1, maxf + 1, K).astype(np.uint32)
+    inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
+    tf[: min(K, 3)] = [1, min(2, maxf), maxf][: min(K, 3)]
+    inf[: min(B, 3)] = [maxf, 1, min(2, maxf)][: min(B, 3)]
+    amp = int(rng.choice([6, 3000, 32767]))
+    tm = rng.integers(-amp, amp + 1, (K, maxf + 1, 12)).astype(np.int16)
+    im = rng.integers(-amp, amp + 1, (B, maxf, 12)).astype(np.int16)
+    valid = (rng.random(K) > 0.15).astype(np.uint8)
+    eng = Engine(max_frames=maxf, device=0)
+    eng.set_templates_dense(tm, tf, valid)
+    assert B * K <= 1024
+    sc, res = _dtw_all_modes(eng, im, inf)
+    pad = np.zeros((1, 12), np.int16)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) if valid[k] else ol.DIS_ERR
+                      for k in range(K)] for b in range(B)], dtype=np.uint32)
+    assert np.array_equal(sc, want), (maxf, K, B)
+    wb = np.array([int(np.argmin(w)) if w.min() != ol.DIS_ERR else 0 for w in want])
+    assert np.array_equal(res["best_tpl"], wb) and np.array_equal(res["min_dis"], want.min(1))
     eng.close()
 
 
@@ -514,7 +568,7 @@ def test_dtw_large_template_stores_match_oracle(K):
     im = rng.integers(-2500, 2500, (B, maxf, 12)).astype(np.int16)
     eng = Engine(max_frames=maxf, device=0)
     eng.set_templates_dense(tm, tf, valid)
-    sc, res = eng.dtw(im, inf)
+    sc, res = _dtw_all_modes(eng, im, inf)
     pad = np.zeros((1, 12), np.int16)
     want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) if valid[k] else ol.DIS_ERR
                       for k in range(K)] for b in range(B)], dtype=np.uint32)
@@ -1303,6 +1357,10 @@ def test_generic_front_end_random_configurations(seed):
     assert np.array_equal(out["scores"], osc), ekw
     for f in ("best_tpl", "min_dis"):
         assert np.array_equal(out["results"][f], ores[f]), (ekw, f)
+    for mode in (2, 1, 0):  # one workgroup per pair (k_dtw_cells, any feature width up to 16) / never / automatic
+        eng.set_small_launch(mode)
+        out2 = eng.recognize(pcm)
+        assert np.array_equal(out2["scores"], osc) and out2["results"].tobytes() == out["results"].tobytes(), (ekw, mode)
     # every VAD segment matched like segment 0 (sr_recognize_segments_batch), and template training into a slot image
     # whose records are n_coef wide (sr_train_store), on the same kernels
     sres, ssc, svd = eng.recognize_segments(pcm[:12])
@@ -1472,7 +1530,7 @@ def test_dtw_generic_fallback_matches_oracle():
     im = rng.integers(-2000, 2000, (B, maxf, 12)).astype(np.int16)
     eng = Engine(max_frames=maxf, device=0)
     eng.set_templates_dense(tm, tf)
-    sc, res = eng.dtw(im, inf)
+    sc, res = _dtw_all_modes(eng, im, inf)
     pad = np.zeros((1, 12), np.int16)
     want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
                     dtype=np.uint32)
@@ -1488,7 +1546,7 @@ def test_dtw_generic_fallback_matches_oracle():
     im = rng.integers(-2000, 2000, (B, maxf, 12)).astype(np.int16)
     eng = Engine(max_frames=maxf, device=0)
     eng.set_templates_dense(tm, tf)
-    sc, res = eng.dtw(im, inf)
+    sc, res = _dtw_all_modes(eng, im, inf)
     want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) for k in range(K)] for b in range(B)],
                     dtype=np.uint32)
     assert np.array_equal(sc, want)

@@ -148,6 +148,18 @@ def test_dtw_limit_interval_form_used_by_the_dp_kernel_and_bench(oracle):
                 for y in range(1, mdl_n + 1):
                     assert (lb <= y <= ub) == (L.sr_oracle_dtw_outside(x, y, in_n, mdl_n) == 0), (in_n, mdl_n, x, y)
                 cells += max(0, min(ub, mdl_n) - max(lb, 1) + 1)
+            # k_dtw_cells evaluates every point the walk could stand on, including the column / row one past a 1-frame
+            # sequence (the do-while of DTW.C:150-188 tests x + 1 and y + 1 before the loop condition is looked at)
+            for x in (in_n + 1, in_n + 2):
+                ub = 2 * x + 1 if x < X1 else ((x + 5 - in_n + 2 * mdl_n) >> 1) - 1
+                lb = (x >> 1) if x < X2 else 2 * x + mdl_n - 2 * in_n - 3
+                for y in range(1, mdl_n + 3):
+                    assert (lb <= y <= ub) == (L.sr_oracle_dtw_outside(x, y, in_n, mdl_n) == 0), (in_n, mdl_n, x, y)
+            for x in range(1, in_n + 1):
+                ub = 2 * x + 1 if x < X1 else ((x + 5 - in_n + 2 * mdl_n) >> 1) - 1
+                lb = (x >> 1) if x < X2 else 2 * x + mdl_n - 2 * in_n - 3
+                for y in (mdl_n + 1, mdl_n + 2):
+                    assert (lb <= y <= ub) == (L.sr_oracle_dtw_outside(x, y, in_n, mdl_n) == 0), (in_n, mdl_n, x, y)
             got, ok = bench.dp_cells_per_pair(in_n, [mdl_n])
             assert ok == 1 and got == cells, (in_n, mdl_n, got, cells)
             n_pairs += 1
