@@ -108,28 +108,46 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
     const int c1s2 = 5 - ((int)in_n - 2 * (int)mdl_n), c2s = ((int)mdl_n - 2 * (int)in_n) - 3;
     auto ub1_of = [&](int xx) { return (xx < X1) ? 2 * xx + 2 : ((xx + c1s2) >> 1); };
     auto lb_of = [&](int xx) { return (xx < X2) ? (xx >> 1) : 2 * xx + c2s; };
-    // ---- every point at once: a wave takes rows px = wave, wave + 16, ..., its lanes the columns py ----
+    // ---- every point at once.  With E[ix][iy] = the candidate "rows ix / iy" (dtw_limit of the point (ix+1, iy+1), then get_dis;
+    // dis_err outside), the point (px, py) needs up = E[px][py+1], right = E[px+1][py], diag = E[px+1][py+1]: three entries of E
+    // per point, but ONE NEW entry per point when a lane keeps a column c = py + 1 and walks down the rows -- its previous
+    // entry is the next point's `up`, the new one its `diag`, and `right` is the new entry of the lane to its left (one DPP
+    // move across the wave).  A wave owns a block of 64 columns (63 points wide: lane 0 only feeds lane 1) and a contiguous
+    // range of rows; the template row of a lane's column stays in registers, the input row is one broadcast LDS read.
     const uint32_t lane = tid & 63, wv = tid >> 6;
-    for (uint32_t px = wv; px < MX; px += kThreads / 64) {
-        const Row16 ci = lds_row(s_in + px * kRowWords), ni = lds_row(s_in + (px + 1) * kRowWords);  // same address in every lane: broadcast
-        const int x = (int)px + 1;
-        const int lbA = lb_of(x), ubA1 = ub1_of(x), lbB = lb_of(x + 1), ubB1 = ub1_of(x + 1);
-        for (uint32_t py = lane; py < MY; py += 64) {
-            const Row16 cm = lds_row(s_md + py * kRowWords), nm = lds_row(s_md + (py + 1) * kRowWords);
-            const int y = (int)py + 1, y1 = y + 1;
-            const bool in_up = (lbA <= y1) & (y1 < ubA1), in_rt = (lbB <= y) & (y < ubB1), in_dg = (lbB <= y1) & (y1 < ubB1);
-            const uint32_t up = in_up ? dis_rows(nm, ci) : SR_DIS_ERR;      // (x, y+1):   get_dis(mdl+12, in),    DTW.C:152
-            const uint32_t right = in_rt ? dis_rows(cm, ni) : SR_DIS_ERR;   // (x+1, y):   get_dis(mdl, in+12),    DTW.C:153
-            const uint32_t diag = in_dg ? dis_rows(nm, ni) : SR_DIS_ERR;    // (x+1, y+1): get_dis(mdl+12, in+12), DTW.C:154
+    const uint32_t n_cb = (MY + 62) / 63;                              // column blocks
+    const uint32_t n_rg = (kThreads / 64) / n_cb ? (kThreads / 64) / n_cb : 1;  // row groups sharing the workgroup's 16 waves
+    const uint32_t rows_per = (MX + n_rg - 1) / n_rg;
+    for (uint32_t unit = wv; unit < n_cb * n_rg; unit += kThreads / 64) {  // (more than 16 column blocks: a wave takes several)
+        const uint32_t cb = unit % n_cb, rg = unit / n_cb;
+        const uint32_t p0 = rg * rows_per, p1 = (p0 + rows_per < MX) ? p0 + rows_per : MX;
+        const uint32_t c = cb * 63 + lane;  // column of E = template row; the lane's points are (ix - 1, c - 1)
+        if (p0 >= p1) continue;
+        const bool col = c <= MY;
+        const Row16 md = lds_row(s_md + (col ? c : 0u) * kRowWords);
+        const int y = (int)c + 1;  // 1-based y of the candidates in column c
+        auto entry = [&](uint32_t ix) {
+            const Row16 ir = lds_row(s_in + ix * kRowWords);  // same address in every lane: broadcast
+            const int x = (int)ix + 1;
+            // (the start point (1, 1) is never a candidate: every candidate has x + 1 >= 2 or y + 1 >= 2)
+            const bool inside = (lb_of(x) <= y) & (y < ub1_of(x));
+            return inside ? dis_rows(md, ir) : SR_DIS_ERR;
+        };
+        uint32_t e_prev = entry(p0);
+        for (uint32_t ix = p0 + 1; ix <= p1; ix++) {
+            const uint32_t diag = entry(ix), up = e_prev;
+            const uint32_t right = dpp_take<0x138, 0xF>(diag);  // wave_shr:1: E[ix][c - 1] from the lane to the left
+            e_prev = diag;
             uint32_t mn = diag;  // DTW.C:156-164
             if (mn > right) mn = right;
             if (mn > up) mn = up;
             const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
+            const uint32_t px = ix - 1, py = c - 1;
             const uint32_t qx = px + ((mv_diag || !mv_up) ? 1u : 0u), qy = py + ((mv_diag || mv_up) ? 1u : 0u);
             const bool stop = !(qx + 1 < in_n && qy + 1 < mdl_n);  // DTW.C:188
             const uint32_t jump = (qx - px) * MY + (qy - py);
             // a root is at most 65 535; dis_err is kept as a flag (cost field 0)
-            s_pt[px * MY + py] = (mn == SR_DIS_ERR ? kErrBit : mn) | (stop ? kStopBit : 0u) | (jump << 18);
+            if (lane != 0 && col) s_pt[px * MY + py] = (mn == SR_DIS_ERR ? kErrBit : mn) | (stop ? kStopBit : 0u) | (jump << 18);
         }
     }
     __syncthreads();

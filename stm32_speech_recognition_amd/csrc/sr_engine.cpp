@@ -124,6 +124,10 @@ struct sr_engine {
     DevBuf<sr_vad_rec> s_vad2;
     // host-buffer pipeline (sr_recognize_batch): upload of chunk c+1 overlaps the kernels of chunk c
     hipStream_t st_copy = nullptr, st_comp = nullptr;
+    // small host-buffer calls (spch_recg: one capture): pinned staging area for the upload, results written by the kernel
+    // straight into pinned host memory -- one stream synchronisation per call instead of a blocking copy each way
+    void *pin_buf = nullptr;
+    size_t pin_cap = 0;
     std::vector<hipEvent_t> ev_chunk;
     // device-resident pipeline (sr_recognize_batch_dev): the batch is cut into chunks that run on a few internal
     // streams, forked from and joined back to the caller's stream, so that the kernels of different chunks overlap
@@ -410,6 +414,7 @@ void sr_destroy(sr_engine *h)
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->pin_buf) (void)hipHostFree(h->pin_buf);
     if (h->st_copy) (void)hipStreamDestroy(h->st_copy);
     if (h->st_comp) (void)hipStreamDestroy(h->st_comp);
     delete h;
@@ -967,6 +972,39 @@ static int recognize_host(sr_engine *h, const void *pcm, uint64_t row_stride, bo
     // thread paces the copies; kernels are only enqueued.  Results come back once, after the last chunk.
     const uint32_t n_chunks = (B >= 2048) ? std::min<uint32_t>(16, B / 1024) : 1;
     const uint8_t *src = (const uint8_t *)pcm;
+    // A few captures (spch_recg's one): two blocking copies cost more than the kernels.  The rows go through a pinned staging
+    // area, the result records are written by the kernel into pinned host memory, and the host waits once.
+    constexpr size_t kPinUpload = 256 * 1024;
+    if (!packed && !h->profiling && h->small_launch != 1 && (uint64_t)B * ds * 2 <= kPinUpload && B <= 256) {
+        const size_t res_off = kPinUpload, need = kPinUpload + 256 * sizeof(sr_result);
+        if (h->pin_cap < need) {
+            if (h->pin_buf) (void)hipHostFree(h->pin_buf);
+            h->pin_buf = nullptr;
+            h->pin_cap = 0;
+            HIP_TRY(hipHostMalloc(&h->pin_buf, need, hipHostMallocMapped));
+            h->pin_cap = need;
+        }
+        if (!h->st_comp) HIP_TRY(hipStreamCreateWithFlags(&h->st_comp, hipStreamNonBlocking));
+        uint8_t *stage = (uint8_t *)h->pin_buf;
+        for (uint32_t b = 0; b < B; b++) {
+            std::memcpy(stage + (size_t)b * ds * 2, src + (size_t)b * src_pitch, (size_t)src_row_bytes);
+            if (ds * 2 > src_row_bytes) std::memset(stage + (size_t)b * ds * 2 + src_row_bytes, 0, (size_t)(ds * 2 - src_row_bytes));
+        }
+        void *d_res = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d_res, stage + res_off, 0));
+        HIP_TRY(hipMemcpyAsync(h->s_pcm.p, stage, (size_t)B * ds * 2, hipMemcpyHostToDevice, h->st_comp));
+        rc = sr_recognize_batch_dev(h, h->s_pcm.p, ds, buf_len, B, (sr_result *)d_res, h->s_scores.p, h->s_mfcc.p, h->s_vad.p, h->st_comp);
+        if (rc) {
+            (void)hipStreamSynchronize(h->st_comp);
+            return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(h->st_comp));
+        std::memcpy(results, stage + res_off, (size_t)B * sizeof(sr_result));
+        if (scores) HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
+        if (mfcc) HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * h->nc * 2, hipMemcpyDeviceToHost));
+        if (vad) HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
+        return SR_OK;
+    }
     if (n_chunks <= 1 || h->profiling) {
         if (packed) {
             HIP_TRY(hipMemcpy2D(h->s_pack.p, dpk, src, src_pitch, src_row_bytes, B, hipMemcpyHostToDevice));
