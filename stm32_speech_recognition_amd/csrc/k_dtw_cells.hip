@@ -8,7 +8,7 @@
 // idle width is spent instead: ONE WORKGROUP PER PAIR first evaluates, for EVERY point (x, y) of the rectangle at once, what
 // the walk would do if it stood there -- the three candidates of DTW.C:152-154 (dtw_limit + get_dis), their minimum
 // (DTW.C:156-164), the move (DTW.C:168-184) and whether the loop ends after it (DTW.C:188) -- packed into one 32-bit word per
-// point in LDS; the walk itself is then one lane chasing those words: one LDS read, two adds and a shift per step.
+// point in LDS; the walk itself is then one lane chasing those words (two steps per word after one more pass): an LDS read, a few adds.
 // Same arithmetic as k_dtw_gen (any feature width up to 16 coefficients, plain template store), so the scores are identical.
 #include "sr_dtw_cells.h"
 #include "sr_dtw_dev.h"
@@ -17,9 +17,13 @@ namespace sr {
 namespace cells {
 constexpr uint32_t kThreads = 1024;
 constexpr uint32_t kRowWords = 9;  // 8 packed coefficient pairs + the squared norm; odd stride: lanes on consecutive rows, distinct banks
-// word of a point: bits 0-15 the step cost (root of the smallest admissible candidate), bit 16 "all three outside" (the cost is
-// dis_err = 2^32 - 1, DTW.C:152-164), bit 17 the walk ends after this step, bits 18-31 the distance to the next point in words
-constexpr uint32_t kErrBit = 1u << 16, kStopBit = 1u << 17;
+// word of a point = what one or two steps of the walk from there add up to:
+//   bits 0-16  the cost (roots of the smallest admissible candidates, each at most 65 535)
+//   bits 17-18 how many of the steps had all three candidates outside (each costs dis_err = 2^32 - 1, DTW.C:152-164)
+//   bit 19     the walk ends after these steps (DTW.C:188)      bit 20  two steps (0: one)
+//   bits 21-31 the distance to the point reached, in words (one step: at most MY + 1 <= 1023)
+constexpr uint32_t kCostMask = 0x1FFFFu, kErrShift = 17, kStopBit = 1u << 19, kTwoBit = 1u << 20, kJumpShift = 21;
+constexpr uint32_t kPairPoints = 16;  // points per thread the two-step pass keeps in registers
 
 struct Row16 {
     uint32_t w[8];
@@ -64,9 +68,9 @@ size_t dtw_cells_lds(uint32_t max_frames, uint32_t tpl_rows)
 }
 bool dtw_cells_fits(const DtwArgs &a)
 {
-    // two rows per sequence at least (the do-while of DTW.C:150-188 reads row 1 even of 1-frame sequences); the jump to the
-    // next point must fit 14 bits; one workgroup's LDS
-    return a.max_frames >= 2 && a.tpl_rows >= 2 && a.tpl_rows + 1 < (1u << 14) && a.n_coef >= 1 && a.n_coef <= 16 &&
+    // two rows per sequence at least (the do-while of DTW.C:150-188 reads row 1 even of 1-frame sequences); the jump over two
+    // steps must fit 11 bits; one workgroup's LDS
+    return a.max_frames >= 2 && a.tpl_rows >= 2 && a.tpl_rows <= 1023 && a.n_coef >= 1 && a.n_coef <= 16 &&
            dtw_cells_lds(a.max_frames, a.tpl_rows) <= 150 * 1024;
 }
 
@@ -84,84 +88,154 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
         ok = a.vad[b].status == SR_ST_OK && in_n != 0;
     }
     const uint32_t mdl_n = a.tpl_frames[k];
-    uint32_t *out = a.scores + (size_t)b * a.K + k;
-    // main.c:283, DTW.C:133-137; counts beyond the allocation (never produced by this library) are not walked
-    if (!(ok && a.tpl_valid[k]) || in_n > mdl_n * 2 || 2 * in_n < mdl_n || in_n > a.max_frames || mdl_n >= a.tpl_rows) {
-        if (tid == 0) *out = SR_DIS_ERR;
-        return;
-    }
-    // rows the walk can touch: x + 1 <= max(in_n, 2), y + 1 <= max(mdl_n, 2) (1-based; row 1 of a 1-frame sequence is the
-    // slack row the reference's do-while reads, DTW.C:150-154)
-    const uint32_t NX = in_n > 1 ? in_n : 2, NY = mdl_n > 1 ? mdl_n : 2;
-    const uint32_t MX = NX - 1, MY = NY - 1;  // points the walk can stand on: px < MX, py < MY (0-based)
-    uint32_t *s_in = sm, *s_md = s_in + NX * kRowWords, *s_pt = s_md + NY * kRowWords;
-    const int16_t *in = a.mfcc + (size_t)b * a.max_frames * nc, *mdl = a.tpl + (size_t)k * a.tpl_stride;
-    for (uint32_t r = tid; r < NX + NY; r += kThreads) {
-        if (r < NX) stage_row(s_in + r * kRowWords, in + (size_t)r * nc, nc);
-        else stage_row(s_md + (r - NX) * kRowWords, mdl + (size_t)(r - NX) * nc, nc);
-    }
-    __syncthreads();
-    const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142 (u16 statics)
-    const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
-    // dtw_limit (DTW.C:76-109) as an interval per column, lb(x) <= y < ub1(x) (see k_dtw_lds; every length pair checked point
-    // by point against the oracle's dtw_limit in tests/test_oracle.py)
-    const int c1s2 = 5 - ((int)in_n - 2 * (int)mdl_n), c2s = ((int)mdl_n - 2 * (int)in_n) - 3;
-    auto ub1_of = [&](int xx) { return (xx < X1) ? 2 * xx + 2 : ((xx + c1s2) >> 1); };
-    auto lb_of = [&](int xx) { return (xx < X2) ? (xx >> 1) : 2 * xx + c2s; };
-    // ---- every point at once.  With E[ix][iy] = the candidate "rows ix / iy" (dtw_limit of the point (ix+1, iy+1), then get_dis;
-    // dis_err outside), the point (px, py) needs up = E[px][py+1], right = E[px+1][py], diag = E[px+1][py+1]: three entries of E
-    // per point, but ONE NEW entry per point when a lane keeps a column c = py + 1 and walks down the rows -- its previous
-    // entry is the next point's `up`, the new one its `diag`, and `right` is the new entry of the lane to its left (one DPP
-    // move across the wave).  A wave owns a block of 64 columns (63 points wide: lane 0 only feeds lane 1) and a contiguous
-    // range of rows; the template row of a lane's column stays in registers, the input row is one broadcast LDS read.
     const uint32_t lane = tid & 63, wv = tid >> 6;
-    const uint32_t n_cb = (MY + 62) / 63;                              // column blocks
-    const uint32_t n_rg = (kThreads / 64) / n_cb ? (kThreads / 64) / n_cb : 1;  // row groups sharing the workgroup's 16 waves
-    const uint32_t rows_per = (MX + n_rg - 1) / n_rg;
-    for (uint32_t unit = wv; unit < n_cb * n_rg; unit += kThreads / 64) {  // (more than 16 column blocks: a wave takes several)
-        const uint32_t cb = unit % n_cb, rg = unit / n_cb;
-        const uint32_t p0 = rg * rows_per, p1 = (p0 + rows_per < MX) ? p0 + rows_per : MX;
-        const uint32_t c = cb * 63 + lane;  // column of E = template row; the lane's points are (ix - 1, c - 1)
-        if (p0 >= p1) continue;
-        const bool col = c <= MY;
-        const Row16 md = lds_row(s_md + (col ? c : 0u) * kRowWords);
-        const int y = (int)c + 1;  // 1-based y of the candidates in column c
-        auto entry = [&](uint32_t ix) {
-            const Row16 ir = lds_row(s_in + ix * kRowWords);  // same address in every lane: broadcast
-            const int x = (int)ix + 1;
-            // (the start point (1, 1) is never a candidate: every candidate has x + 1 >= 2 or y + 1 >= 2)
-            const bool inside = (lb_of(x) <= y) & (y < ub1_of(x));
-            return inside ? dis_rows(md, ir) : SR_DIS_ERR;
-        };
-        uint32_t e_prev = entry(p0);
-        for (uint32_t ix = p0 + 1; ix <= p1; ix++) {
-            const uint32_t diag = entry(ix), up = e_prev;
-            const uint32_t right = dpp_take<0x138, 0xF>(diag);  // wave_shr:1: E[ix][c - 1] from the lane to the left
-            e_prev = diag;
-            uint32_t mn = diag;  // DTW.C:156-164
-            if (mn > right) mn = right;
-            if (mn > up) mn = up;
-            const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
-            const uint32_t px = ix - 1, py = c - 1;
-            const uint32_t qx = px + ((mv_diag || !mv_up) ? 1u : 0u), qy = py + ((mv_diag || mv_up) ? 1u : 0u);
-            const bool stop = !(qx + 1 < in_n && qy + 1 < mdl_n);  // DTW.C:188
-            const uint32_t jump = (qx - px) * MY + (qy - py);
-            // a root is at most 65 535; dis_err is kept as a flag (cost field 0)
-            if (lane != 0 && col) s_pt[px * MY + py] = (mn == SR_DIS_ERR ? kErrBit : mn) | (stop ? kStopBit : 0u) | (jump << 18);
+    uint32_t score = SR_DIS_ERR;
+    // main.c:283, DTW.C:133-137; counts beyond the allocation (never produced by this library) are not walked
+    if (ok && a.tpl_valid[k] && !(in_n > mdl_n * 2 || 2 * in_n < mdl_n || in_n > a.max_frames || mdl_n >= a.tpl_rows)) {  // workgroup-uniform
+        // rows the walk can touch: x + 1 <= max(in_n, 2), y + 1 <= max(mdl_n, 2) (1-based; row 1 of a 1-frame sequence is the
+        // slack row the reference's do-while reads, DTW.C:150-154)
+        const uint32_t NX = in_n > 1 ? in_n : 2, NY = mdl_n > 1 ? mdl_n : 2;
+        const uint32_t MX = NX - 1, MY = NY - 1;  // points the walk can stand on: px < MX, py < MY (0-based)
+        uint32_t *s_in = sm, *s_md = s_in + NX * kRowWords, *s_pt = s_md + NY * kRowWords;
+        const int16_t *in = a.mfcc + (size_t)b * a.max_frames * nc, *mdl = a.tpl + (size_t)k * a.tpl_stride;
+        for (uint32_t r = tid; r < NX + NY; r += kThreads) {
+            if (r < NX) stage_row(s_in + r * kRowWords, in + (size_t)r * nc, nc);
+            else stage_row(s_md + (r - NX) * kRowWords, mdl + (size_t)(r - NX) * nc, nc);
+        }
+        __syncthreads();
+        const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142 (u16 statics)
+        const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
+        // dtw_limit (DTW.C:76-109) as an interval per column, lb(x) <= y < ub1(x) (see k_dtw_lds; every length pair checked point
+        // by point against the oracle's dtw_limit in tests/test_oracle.py)
+        const int c1s2 = 5 - ((int)in_n - 2 * (int)mdl_n), c2s = ((int)mdl_n - 2 * (int)in_n) - 3;
+        auto ub1_of = [&](int xx) { return (xx < X1) ? 2 * xx + 2 : ((xx + c1s2) >> 1); };
+        auto lb_of = [&](int xx) { return (xx < X2) ? (xx >> 1) : 2 * xx + c2s; };
+        // ---- every point at once.  With E[ix][iy] = the candidate "rows ix / iy" (dtw_limit of the point (ix+1, iy+1), then get_dis;
+        // dis_err outside), the point (px, py) needs up = E[px][py+1], right = E[px+1][py], diag = E[px+1][py+1]: three entries of E
+        // per point, but ONE NEW entry per point when a lane keeps a column c = py + 1 and walks down the rows -- its previous
+        // entry is the next point's `up`, the new one its `diag`, and `right` is the new entry of the lane to its left (one DPP
+        // move across the wave).  A wave owns a block of 64 columns (63 points wide: lane 0 only feeds lane 1) and a contiguous
+        // range of rows; the template row of a lane's column stays in registers, the input row is one broadcast LDS read.
+        const uint32_t n_cb = (MY + 62) / 63;                              // column blocks
+        const uint32_t n_rg = (kThreads / 64) / n_cb ? (kThreads / 64) / n_cb : 1;  // row groups sharing the workgroup's 16 waves
+        const uint32_t rows_per = (MX + n_rg - 1) / n_rg;
+        for (uint32_t unit = wv; unit < n_cb * n_rg; unit += kThreads / 64) {  // (more than 16 column blocks: a wave takes several)
+            const uint32_t cb = unit % n_cb, rg = unit / n_cb;
+            const uint32_t p0 = rg * rows_per, p1 = (p0 + rows_per < MX) ? p0 + rows_per : MX;
+            const uint32_t c = cb * 63 + lane;  // column of E = template row; the lane's points are (ix - 1, c - 1)
+            if (p0 >= p1) continue;
+            const bool col = c <= MY;
+            const Row16 md = lds_row(s_md + (col ? c : 0u) * kRowWords);
+            const int y = (int)c + 1;  // 1-based y of the candidates in column c
+            auto entry = [&](uint32_t ix) {
+                const Row16 ir = lds_row(s_in + ix * kRowWords);  // same address in every lane: broadcast
+                const int x = (int)ix + 1;
+                // (the start point (1, 1) is never a candidate: every candidate has x + 1 >= 2 or y + 1 >= 2)
+                const bool inside = (lb_of(x) <= y) & (y < ub1_of(x));
+                return inside ? dis_rows(md, ir) : SR_DIS_ERR;
+            };
+            uint32_t e_prev = entry(p0);
+            for (uint32_t ix = p0 + 1; ix <= p1; ix++) {
+                const uint32_t diag = entry(ix), up = e_prev;
+                const uint32_t right = dpp_take<0x138, 0xF>(diag);  // wave_shr:1: E[ix][c - 1] from the lane to the left
+                e_prev = diag;
+                uint32_t mn = diag;  // DTW.C:156-164
+                if (mn > right) mn = right;
+                if (mn > up) mn = up;
+                const bool mv_diag = (mn == diag), mv_up = !mv_diag && (mn == up);  // DTW.C:168-184
+                const uint32_t px = ix - 1, py = c - 1;
+                const uint32_t qx = px + ((mv_diag || !mv_up) ? 1u : 0u), qy = py + ((mv_diag || mv_up) ? 1u : 0u);
+                const bool stop = !(qx + 1 < in_n && qy + 1 < mdl_n);  // DTW.C:188
+                const uint32_t jump = (qx - px) * MY + (qy - py);
+                // a root is at most 65 535; dis_err is kept as a flag (cost field 0)
+                const uint32_t word = (mn == SR_DIS_ERR ? (1u << kErrShift) : mn) | (stop ? kStopBit : 0u) | (jump << kJumpShift);
+                if (lane != 0 && col) s_pt[px * MY + py] = word;
+            }
+        }
+        __syncthreads();
+        // ---- two steps per word: every point absorbs the point its step leads to (all reads, a barrier, all writes: in place).
+        // The walk below is a chain of dependent LDS reads, ~110 cycles each; this halves it for one more pass over the points.
+        const uint32_t npts = MX * MY;
+        if (npts <= kPairPoints * kThreads) {
+            uint32_t keep[kPairPoints];
+#pragma unroll
+            for (uint32_t i = 0; i < kPairPoints; i++) {
+                const uint32_t c = tid + i * kThreads;
+                uint32_t w = 0;
+                if (c < npts) {
+                    w = s_pt[c];
+                    if (!(w & kStopBit)) {
+                        const uint32_t w2 = s_pt[c + (w >> kJumpShift)];
+                        // costs, outside counts and jumps add up field by field (no carry: 2 x 65 535 < 2^17, 1 + 1 < 4, the jump
+                        // bound is checked by dtw_cells_fits); the second step decides whether the walk ends
+                        w = (w + (w2 & ~(kStopBit | kTwoBit))) | (w2 & kStopBit) | kTwoBit;
+                    }
+                }
+                keep[i] = w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t i = 0; i < kPairPoints; i++) {
+                const uint32_t c = tid + i * kThreads;
+                if (c < npts) s_pt[c] = keep[i];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            // ---- the walk: DTW.C:146-191 as a chase through the points ----
+            uint32_t dis = dis_rows(lds_row(s_in), lds_row(s_md));  // DTW.C:146
+            uint32_t step = 1, at = 0, w;
+            do {
+                w = s_pt[at];
+                dis += (w & kCostMask) - ((w >> kErrShift) & 3u);  // + dis_err = - 1 in the u32 ring (DTW.C:186)
+                at += w >> kJumpShift;
+                step += 1 + ((w >> 20) & 1u);
+            } while (!(w & kStopBit));
+            step &= 0xFFFF;  // u16 step (DTW.C:126)
+            score = dis / step;  // DTW.C:191
         }
     }
-    __syncthreads();
-    if (tid != 0) return;
-    // ---- the walk: DTW.C:146-191 as a chase through the points ----
-    uint32_t dis = dis_rows(lds_row(s_in), lds_row(s_md));  // DTW.C:146
-    uint32_t step = 1, at = 0, w;
-    do {
-        w = s_pt[at];
-        dis += (w & 0xFFFFu) - ((w >> 16) & 1u);  // + dis_err = - 1 in the u32 ring (DTW.C:186)
-        at += w >> 18;
-        step = (step + 1) & 0xFFFF;  // u16 step
-    } while (!(w & kStopBit));
-    *out = dis / step;  // DTW.C:191
+    if (wv != 0) return;
+    uint32_t *sc = a.scores + (size_t)b * a.K;
+    if (lane == 0) __hip_atomic_store(sc + k, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!a.results || !a.pair_count) return;
+    // ---- the slot scan of spch_recg (main.c:276-295) by whichever workgroup of the utterance finishes last: the count of
+    // finished pairs is taken after the score is out (release / acquire at device scope), the scores are read back coherently,
+    // and the counter is left at zero for the next launch.  Strict '<' in slot order: the first minimum wins; all dis_err ->
+    // slot 0 (see k_argmin).
+    uint32_t last = 0;
+    if (lane == 0) last = __hip_atomic_fetch_add(a.pair_count + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == a.K - 1 ? 1u : 0u;
+    if (!__builtin_amdgcn_readfirstlane((int)last)) return;
+    uint32_t best = SR_DIS_ERR, idx = 0xFFFFFFFFu;
+    for (uint32_t kk = lane; kk < a.K; kk += 64) {
+        const uint32_t d = __hip_atomic_load(sc + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d < best) {
+            best = d;
+            idx = kk;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t ob = __shfl_xor(best, d, 64), oi = __shfl_xor(idx, d, 64);
+        if (ob < best || (ob == best && oi < idx)) {
+            best = ob;
+            idx = oi;
+        }
+    }
+    if (lane == 0) {
+        sr_result r;
+        r.best_tpl = (best == SR_DIS_ERR) ? 0u : idx;
+        r.min_dis = best;
+        if (a.in_frames) {
+            r.frm_num = a.in_frames[b];
+            r.status = SR_ST_OK;
+        } else {
+            r.frm_num = a.vad[b].frm_num;
+            r.status = a.vad[b].status;
+        }
+        a.results[b] = r;
+        __hip_atomic_store(a.pair_count + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 void launch_dtw_cells(const DtwArgs &a, hipStream_t s)

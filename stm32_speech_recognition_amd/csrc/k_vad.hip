@@ -41,6 +41,10 @@ void launch_vad_other(const VadArgs &a, hipStream_t s);
 void launch_vad(const VadArgs &a, hipStream_t s)
 {
     if (!a.B) return;
+    if (a.wide) {
+        launch_vad_wide(a, s);
+        return;
+    }
     const dim3 grid((a.B + kVadWaves - 1) / kVadWaves), block(64 * kVadWaves);
     const bool own_thresholds = a.atap_in == nullptr;  // noise_atap runs in the kernel: mid is a 16-bit quantity
     if (a.frame_len != 160 && a.frame_len != 320) {

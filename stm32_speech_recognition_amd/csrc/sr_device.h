@@ -57,6 +57,7 @@ struct VadArgs {
     uint32_t frame_len;      // 160 (reference), 320 (extension) or one of the generic front end's framings (k_vad_gen.hip)
     uint32_t v_durmin;       // VAD.C:72-73: 80 ms / (frame_time - frame_mov_t) frames (8 at 20 / 10 ms)
     uint32_t s_durmax;       // VAD.C:74-75: 110 ms / (frame_time - frame_mov_t) frames (11)
+    uint32_t wide;           // 1: a workgroup of four waves per capture (k_vad_wide.hip; small launches), 0: one wave per capture
 };
 
 struct MfccArgs {
@@ -101,6 +102,7 @@ struct DtwArgs {
     uint32_t lds_kc;              // templates per k_dtw_lds workgroup (dtw_lds_pick_u); the store is walked in K / lds_kc chunks
     uint32_t n_coef;              // s16 per feature row: 12 everywhere except the GENERIC front end (-> k_dtw_gen when != 12)
     uint32_t dp_lanes;            // k_dtw_dp only: lanes per pair of the band kernel (4 / 8 / 16; 0 = default 8; 1 = k_dtw_dp_wave64)
+    uint32_t *pair_count;         // k_dtw_cells only: [B] zeroed counters of finished pairs (the last one does the slot scan); may be NULL
 };
 
 // get_mdl (DTW.C:217-296): P independent pairs
@@ -120,6 +122,7 @@ struct GetMdlArgs {
 void launch_get_mdl(const GetMdlArgs &a, hipStream_t s);
 
 void launch_vad(const VadArgs &a, hipStream_t s);
+void launch_vad_wide(const VadArgs &a, hipStream_t s);  // k_vad_wide.hip
 bool vad_framing_supported(uint32_t frame_len, uint32_t hop);  // the VAD kernel is instantiated per framing
 void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
                            uint32_t frame_len, uint32_t hop, hipStream_t s);

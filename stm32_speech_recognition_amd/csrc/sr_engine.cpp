@@ -89,6 +89,9 @@ struct DevBuf {
 
 using namespace sr;
 
+// utterances of one call whose slot scan k_dtw_cells can do itself (one counter each); beyond that k_argmin runs as usual
+static constexpr uint32_t kPairCounters = 65536;
+
 struct sr_engine {
     sr_config cfg;
     int device = 0;
@@ -122,6 +125,7 @@ struct sr_engine {
     DevBuf<uint32_t> s_u32a, s_u32b;
     DevBuf<sr_atap> s_atap;
     DevBuf<sr_vad_rec> s_vad2;
+    DevBuf<uint32_t> s_pcnt;  // k_dtw_cells: finished-pair counters per utterance of a call, zero between launches (kPairCounters)
     // host-buffer pipeline (sr_recognize_batch): upload of chunk c+1 overlaps the kernels of chunk c
     hipStream_t st_copy = nullptr, st_comp = nullptr;
     // small host-buffer calls (spch_recg: one capture): pinned staging area for the upload, results written by the kernel
@@ -379,6 +383,10 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->dev.tri_odd32 = (const uint32_t *)(base + parts[11].off);
     h->dev.tie_delta = (const int8_t *)(base + parts[12].off);
     h->dev.hamm_pk = (const uint32_t *)(base + parts[13].off);
+    if (h->s_pcnt.reserve(kPairCounters) != SR_OK || hipMemset(h->s_pcnt.p, 0, kPairCounters * sizeof(uint32_t)) != hipSuccess) {
+        sr_destroy(h);
+        return fail(SR_ERR_HIP, "pair counters");
+    }
     *out = h;
     return SR_OK;
 }
@@ -406,6 +414,7 @@ void sr_destroy(sr_engine *h)
     h->s_u32b.release();
     h->s_atap.release();
     h->s_vad2.release();
+    h->s_pcnt.release();
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     for (auto &e : h->ev_call) (void)hipEventDestroy(e);
     for (auto &e : h->ev_chunk) (void)hipEventDestroy(e);
@@ -685,8 +694,10 @@ static int check_pcm(const sr_engine *h, const uint16_t *pcm, uint64_t stride, u
 static VadArgs vad_args(const sr_engine *h, const uint16_t *pcm, uint64_t stride, uint32_t buf_len, uint32_t noise_len, uint32_t B,
                         sr_vad_rec *vad, const sr_atap *atap_in = nullptr, uint64_t *dbg = nullptr)
 {
+    // fewer captures than CUs: a workgroup of four waves per capture instead of one wave (k_vad_wide; same records)
+    const uint32_t wide = (h->small_launch != 1 && B < 256) ? 1u : 0u;
     return VadArgs{pcm, stride, buf_len, noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, vad, atap_in, dbg,
-                   h->frame_len, h->v_durmin, h->s_durmax};
+                   h->frame_len, h->v_durmin, h->s_durmax, wide};
 }
 
 int sr_vad_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
@@ -770,6 +781,7 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.lds_kc = h->dtw_kc;
     a.n_coef = h->nc;
     a.dp_lanes = h->dp_lanes;
+    a.pair_count = nullptr;
     return a;
 }
 
@@ -785,12 +797,17 @@ static uint64_t small_launch_pairs(const DtwArgs &a)
     const uint64_t per_cu = std::min<uint64_t>(4, std::max<uint64_t>(1, 160 * 1024 / lds));
     return 512 * per_cu;
 }
-static void launch_dtw_auto(const sr_engine *h, const DtwArgs &a, hipStream_t s)
+// returns true when the slot scan (argmin) has been done as well: k_dtw_cells with result records asked for and the utterances
+// b0 .. b0 + B of the call within the counters
+static bool launch_dtw_auto(const sr_engine *h, DtwArgs &a, uint32_t b0, hipStream_t s)
 {
-    if (h->small_launch != 1 && dtw_cells_fits(a) && (h->small_launch == 2 || (uint64_t)a.B * a.K <= small_launch_pairs(a)))
+    if (h->small_launch != 1 && dtw_cells_fits(a) && (h->small_launch == 2 || (uint64_t)a.B * a.K <= small_launch_pairs(a))) {
+        a.pair_count = (a.results && (uint64_t)b0 + a.B <= kPairCounters) ? h->s_pcnt.p + b0 : nullptr;
         launch_dtw_cells(a, s);
-    else
-        launch_dtw(a, s);
+        return a.pair_count != nullptr;
+    }
+    launch_dtw(a, s);
+    return false;
 }
 
 int sr_dtw_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_vad, uint32_t B, uint32_t *d_scores,
@@ -800,8 +817,7 @@ int sr_dtw_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_va
     if (!h->K) return fail(SR_ERR_NO_TEMPLATES, "no templates set");
     ENTER_DEVICE(h);
     DtwArgs a = dtw_args(h, d_mfcc, d_vad, nullptr, B, d_scores, d_results);
-    launch_dtw_auto(h, a, (hipStream_t)stream);
-    if (d_results) launch_argmin(a, (hipStream_t)stream);
+    if (!launch_dtw_auto(h, a, 0, (hipStream_t)stream) && d_results) launch_argmin(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SR_OK;
 }
@@ -872,9 +888,9 @@ int sr_recognize_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_str
         launch_mfcc(mfcc_args(h, pc, pcm_stride, n, vc, mc), sc);
         if (prof) HIP_TRY(hipEventRecord(ev[2], sc));
         DtwArgs da = dtw_args(h, mc, vc, nullptr, n, d_scores + (size_t)b0 * h->K, d_results + b0);
-        launch_dtw_auto(h, da, sc);
+        const bool scanned = launch_dtw_auto(h, da, b0, sc);
         if (prof) HIP_TRY(hipEventRecord(ev[3], sc));
-        launch_argmin(da, sc);
+        if (!scanned) launch_argmin(da, sc);
         if (prof) HIP_TRY(hipEventRecord(ev[4], sc));
     }
     if (n_chunks > 1) {
@@ -923,8 +939,7 @@ int sr_recognize_segments_batch_dev(sr_engine *h, const uint16_t *d_pcm, uint64_
         launch_mfcc(mfcc_args(h, d_pcm, pcm_stride, B, h->s_vad2.p, h->s_mfcc.p), s);
         DtwArgs da = dtw_args(h, h->s_mfcc.p, h->s_vad2.p, nullptr, B, d_scores + (size_t)sg * B * h->K,
                               d_results + (size_t)sg * B);
-        launch_dtw_auto(h, da, s);
-        launch_argmin(da, s);
+        if (!launch_dtw_auto(h, da, 0, s)) launch_argmin(da, s);
     }
     HIP_TRY(hipGetLastError());
     return SR_OK;
@@ -1242,8 +1257,7 @@ int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames
     HIP_TRY(hipMemcpy(h->s_mfcc.p, in_mfcc, msz * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->s_u32a.p, in_frames, (size_t)B * 4, hipMemcpyHostToDevice));
     DtwArgs a = dtw_args(h, h->s_mfcc.p, nullptr, h->s_u32a.p, B, h->s_scores.p, h->s_results.p);
-    launch_dtw_auto(h, a, nullptr);
-    launch_argmin(a, nullptr);
+    if (!launch_dtw_auto(h, a, 0, nullptr)) launch_argmin(a, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
     if (results) HIP_TRY(hipMemcpy(results, h->s_results.p, (size_t)B * sizeof(sr_result), hipMemcpyDeviceToHost));

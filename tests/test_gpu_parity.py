@@ -62,8 +62,12 @@ def test_fft_q15_matches_golden(eng119, golden):
     assert np.array_equal(got, golden["fft_out"])
 
 
-def test_vad_matches_golden(eng119, golden):
+@pytest.mark.parametrize("mode", [1, 0])
+def test_vad_matches_golden(eng119, golden, mode):
+    """mode 1: one wave per capture (k_vad); mode 0: the fixture has fewer captures than CUs -> four waves per capture (k_vad_wide)"""
+    eng119.set_small_launch(mode)
     vd = eng119.vad(golden["pcm"])
+    eng119.set_small_launch(0)
     assert np.array_equal(np.stack([vd["mid_val"], vd["n_thl"], vd["z_thl"], vd["s_thl"]], 1), golden["atap"])
     assert np.array_equal(vd["seg"], golden["seg"])
     assert np.array_equal(vd["frm_num"], golden["frm_num"])
@@ -418,7 +422,11 @@ def test_vad_stress_matches_oracle(eng119, oracle):
         if b % 7 == 0:
             sig[rng.integers(2400, S):] += rng.choice([-60, 60])  # DC step: band re-entry from one side only
         pcm[b] = np.clip(2048 + sig, 0, 4095).astype(np.uint16)
+    eng119.set_small_launch(1)   # one wave per capture (k_vad), whatever the launch size
     vd = eng119.vad(pcm)
+    eng119.set_small_launch(0)   # fewer captures than CUs: four waves per capture (k_vad_wide)
+    vdw = eng119.vad(pcm)
+    assert vd.tobytes() == vdw.tobytes()
     nseg = 0
     for b in range(B):
         rc, a = oracle.noise_atap(pcm[b])
