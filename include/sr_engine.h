@@ -280,12 +280,20 @@ int sr_allgather_scores(void *nccl_comm, const uint32_t *d_scores, uint32_t *d_a
  * overlap with the other chunks' kernels), ms[4] = one whole call on the caller's stream (fork -> join).
  * sr_get_stage_launches: launches of each kernel per call (= chunks). */
 int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t max_chunks); /* same knobs at run time */
-/* Small launches -- one capture against the store (spch_recg, main.c:276-295), one dtw() call, a handful of captures -- are
- * latency-bound: dtw (DTW.C:120-192) is a serial walk, and a few hundred walks leave the GPU idle.  Up to 1024 pairs per
- * launch the engine therefore scores every pair with its own workgroup (k_dtw_cells: all points of the in x mdl rectangle
- * evaluated at once, then one lane follows the precomputed moves), provided the rectangle fits a workgroup's LDS
- * (max_frames x longest template <= ~36 000 points; the firmware's 119 x 119 does).  Same scores bit for bit.
- * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = whenever the rectangle fits, whatever the launch size. */
+/* Small launches -- one capture against the store (spch_recg, main.c:276-295), one dtw() / get_mfcc() call, a handful of
+ * captures -- are latency-bound: every stage of the path is a serial chain per capture (VAD's state across frames, a wave's
+ * frames, dtw's walk), and a few of them leave the GPU idle.  The engine then spends the idle width instead:
+ *   VAD   fewer than 256 captures: a workgroup of four waves per capture (k_vad_wide) instead of one wave;
+ *   MFCC  fewer than 256 work items: 8 frames per workgroup instead of 64 (reference front end);
+ *   DTW   up to 2048 pairs per launch (1024 per workgroup that fits a CU's LDS): every pair gets its own workgroup
+ *         (k_dtw_cells: all points of the in x mdl rectangle evaluated at once, then one lane follows the precomputed moves,
+ *         and the last pair of an utterance does the slot scan), provided the rectangle fits a workgroup's LDS
+ *         (max_frames x (longest template + 1) <= ~36 000 points and at most 1022 template frames; the firmware's 119 x 119 does);
+ *   host  sr_recognize_batch with at most 256 KB of captures: pinned staging, results written to pinned host memory.
+ * Same results bit for bit (tests run the DTW / VAD / recognition cases in every mode).  One 16 000-sample capture against
+ * 80 slots: 242 us -> 66 us per spch_recg call on an otherwise idle MI355X (profiles/, latency block of bench.py).
+ * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = the DTW form whenever the rectangle fits, whatever
+ * the launch size. */
 int sr_set_small_launch(sr_engine *h, int mode);
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
