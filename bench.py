@@ -478,7 +478,9 @@ def latency_block(local_rank, n_utt=64):
       get_mfcc       one segment -> v_ftr_tag (MFCC.C:86-191)
       dtw slot scan  main.c:279-291's loop: 80 dtw() calls for one input record (the symbol scores the record against every
                      cached model in ONE launch, the other 79 calls are look-ups)
-      sr_recognize_batch_dev at B = 1, 16, 256 on device-resident captures, synchronised after every call"""
+      sr_recognize_batch_dev at B = 1, 16, 256 on device-resident captures, synchronised after every call
+    Launches this small take the engine's small-launch forms (k_vad_wide, 8-frame tiles, k_dtw_cells; sr_set_small_launch);
+    `*_batch_kernels_us` is the same call with them switched off."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     from stm32_speech_recognition_amd import compat
@@ -525,6 +527,19 @@ def latency_block(local_rank, n_utt=64):
     with ClockSampler(period=0.002) as clk:  # what the shader clock does under one-call-at-a-time load
         out["spch_recg_us"] = us(f_spch, n_utt, "spch_recg")
     out["sclk_during_spch_recg"] = clk.summary()
+    # the same call with the small-launch forms switched off (sr_set_small_launch mode 1: one wave per capture in VAD, 64 frames
+    # per frame-kernel workgroup, the batch DTW kernel + k_argmin, blocking copies): what the call cost before they existed
+    import ctypes as C
+    from stm32_speech_recognition_amd.engine import load_library
+    L = load_library()
+    L.sr_compat_engine.restype = C.c_void_p
+    ce = C.c_void_p(L.sr_compat_engine())
+    g_on = list(g)
+    L.sr_set_small_launch(ce, C.c_int(1))
+    out["spch_recg_batch_kernels_us"] = us(f_spch, n_utt)
+    L.sr_set_small_launch(ce, C.c_int(0))
+    out["spch_recg_small_launch_identical"] = bool(all(g_on[i] == g[i] for i in range(n_utt)))
+    compat.spch_recg(pcm[0])
     if ref is not None:
         def f_rspch(i):
             r[i] = ref.spch_recg(pcm[i], store)
@@ -586,6 +601,10 @@ def latency_block(local_rank, n_utt=64):
         sm = eng.stage_ms()
         eng.set_profiling(False)
         out[f"sr_recognize_batch_dev_B{Bs}_kernel_us"] = {k: sm[k] * 1e3 for k in ("vad", "mfcc", "dtw", "argmin", "total")}
+        if Bs == 1:  # the batch kernels on the same call (small-launch mode 1)
+            eng.set_small_launch(1)
+            out["sr_recognize_batch_dev_B1_batch_kernels_us"] = us(f_dev, 50)
+            eng.set_small_launch(0)
     out["p90_us"] = p90
     eng.close()
     return out

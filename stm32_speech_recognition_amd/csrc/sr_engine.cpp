@@ -949,6 +949,32 @@ int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_
                                 sr_result *results, uint32_t *scores, sr_vad_rec *vad);
 
 // ---- host-buffer wrappers (stage through HBM) --------------------------------------------------------
+// Pinned host area of the small host-buffer calls (spch_recg / get_mfcc: one capture): captures staged for the upload | result
+// records the kernel writes directly | per-utterance records for the frame kernel | feature rows on their way back.  One
+// stream synchronisation per call instead of a blocking copy in each direction.
+static constexpr size_t kPinUpload = 256 * 1024, kPinMaxB = 256, kPinRes = kPinUpload, kPinRecs = kPinRes + kPinMaxB * sizeof(sr_result),
+                        kPinMfcc = kPinRecs + kPinMaxB * sizeof(sr_vad_rec), kPinMfccBytes = 512 * 1024, kPinTotal = kPinMfcc + kPinMfccBytes;
+static int ensure_pin(sr_engine *h)
+{
+    if (h->pin_cap < kPinTotal) {
+        if (h->pin_buf) (void)hipHostFree(h->pin_buf);
+        h->pin_buf = nullptr;
+        h->pin_cap = 0;
+        HIP_TRY(hipHostMalloc(&h->pin_buf, kPinTotal, hipHostMallocMapped));
+        h->pin_cap = kPinTotal;
+    }
+    if (!h->st_comp) HIP_TRY(hipStreamCreateWithFlags(&h->st_comp, hipStreamNonBlocking));
+    return SR_OK;
+}
+// rows of buf_len samples into the staging area at the device pitch ds (samples), the pad zeroed
+static void stage_rows(uint8_t *stage, const uint8_t *src, uint64_t src_pitch, uint64_t row_bytes, uint64_t ds, uint32_t B)
+{
+    for (uint32_t b = 0; b < B; b++) {
+        std::memcpy(stage + (size_t)b * ds * 2, src + (size_t)b * src_pitch, (size_t)row_bytes);
+        if (ds * 2 > row_bytes) std::memset(stage + (size_t)b * ds * 2 + row_bytes, 0, (size_t)(ds * 2 - row_bytes));
+    }
+}
+
 static int stage_pcm(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                      uint64_t *dev_stride)
 {
@@ -989,22 +1015,11 @@ static int recognize_host(sr_engine *h, const void *pcm, uint64_t row_stride, bo
     const uint8_t *src = (const uint8_t *)pcm;
     // A few captures (spch_recg's one): two blocking copies cost more than the kernels.  The rows go through a pinned staging
     // area, the result records are written by the kernel into pinned host memory, and the host waits once.
-    constexpr size_t kPinUpload = 256 * 1024;
-    if (!packed && !h->profiling && h->small_launch != 1 && (uint64_t)B * ds * 2 <= kPinUpload && B <= 256) {
-        const size_t res_off = kPinUpload, need = kPinUpload + 256 * sizeof(sr_result);
-        if (h->pin_cap < need) {
-            if (h->pin_buf) (void)hipHostFree(h->pin_buf);
-            h->pin_buf = nullptr;
-            h->pin_cap = 0;
-            HIP_TRY(hipHostMalloc(&h->pin_buf, need, hipHostMallocMapped));
-            h->pin_cap = need;
-        }
-        if (!h->st_comp) HIP_TRY(hipStreamCreateWithFlags(&h->st_comp, hipStreamNonBlocking));
+    if (!packed && !h->profiling && h->small_launch != 1 && (uint64_t)B * ds * 2 <= kPinUpload && B <= kPinMaxB) {
+        if ((rc = ensure_pin(h))) return rc;
+        const size_t res_off = kPinRes;
         uint8_t *stage = (uint8_t *)h->pin_buf;
-        for (uint32_t b = 0; b < B; b++) {
-            std::memcpy(stage + (size_t)b * ds * 2, src + (size_t)b * src_pitch, (size_t)src_row_bytes);
-            if (ds * 2 > src_row_bytes) std::memset(stage + (size_t)b * ds * 2 + src_row_bytes, 0, (size_t)(ds * 2 - src_row_bytes));
-        }
+        stage_rows(stage, src, src_pitch, src_row_bytes, ds, B);
         void *d_res = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&d_res, stage + res_off, 0));
         HIP_TRY(hipMemcpyAsync(h->s_pcm.p, stage, (size_t)B * ds * 2, hipMemcpyHostToDevice, h->st_comp));
@@ -1180,8 +1195,29 @@ int sr_mfcc_batch_status(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride,
         if (frm_num) frm_num[b] = r.frm_num;
         if (status) status[b] = r.status;
     }
-    uint64_t ds = 0;
-    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
+    uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
+    const size_t mbytes = (size_t)B * h->cfg.max_frames * h->nc * 2;
+    int rc;
+    if (h->small_launch != 1 && B <= kPinMaxB && (uint64_t)B * ds * 2 <= kPinUpload && mbytes <= kPinMfccBytes) {
+        // a few segments (get_mfcc: one): through the pinned area, one synchronisation (see ensure_pin)
+        if ((rc = ensure_pin(h))) return rc;
+        if ((rc = h->s_pcm.reserve((size_t)B * ds))) return rc;
+        if ((rc = h->s_vad.reserve(B))) return rc;
+        if ((rc = h->s_mfcc.reserve(mbytes / 2))) return rc;
+        uint8_t *pin = (uint8_t *)h->pin_buf;
+        stage_rows(pin, (const uint8_t *)pcm, pcm_stride * 2, (uint64_t)buf_len * 2, ds, B);
+        std::memcpy(pin + kPinRecs, recs.data(), (size_t)B * sizeof(sr_vad_rec));
+        HIP_TRY(hipMemcpyAsync(h->s_pcm.p, pin, (size_t)B * ds * 2, hipMemcpyHostToDevice, h->st_comp));
+        HIP_TRY(hipMemcpyAsync(h->s_vad.p, pin + kPinRecs, (size_t)B * sizeof(sr_vad_rec), hipMemcpyHostToDevice, h->st_comp));
+        rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, B, h->s_vad.p, h->s_mfcc.p, h->st_comp);
+        if (!rc && hipMemcpyAsync(pin + kPinMfcc, h->s_mfcc.p, mbytes, hipMemcpyDeviceToHost, h->st_comp) != hipSuccess)
+            rc = fail(SR_ERR_HIP, "hipMemcpyAsync");
+        HIP_TRY(hipStreamSynchronize(h->st_comp));
+        if (rc) return rc;
+        std::memcpy(mfcc, pin + kPinMfcc, mbytes);
+        return SR_OK;
+    }
+    rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
     if (rc) return rc;
     if ((rc = h->s_vad.reserve(B))) return rc;
     if ((rc = h->s_mfcc.reserve((size_t)B * h->cfg.max_frames * h->nc))) return rc;
