@@ -283,7 +283,7 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
 /* Small launches -- one capture against the store (spch_recg, main.c:276-295), one dtw() / get_mfcc() call, a handful of
  * captures -- are latency-bound: every stage of the path is a serial chain per capture (VAD's state across frames, a wave's
  * frames, dtw's walk), and a few of them leave the GPU idle.  The engine then spends the idle width instead:
- *   VAD   fewer than 256 captures: a workgroup of four waves per capture (k_vad_wide) instead of one wave;
+ *   VAD   fewer than 1024 captures: a workgroup of four waves per capture (k_vad_wide) instead of one wave;
  *   MFCC  fewer than 256 work items: 8 frames per workgroup instead of 64 (reference front end);
  *   DTW   up to 2048 pairs per launch (1024 per workgroup that fits a CU's LDS): every pair gets its own workgroup
  *         (k_dtw_cells: all points of the in x mdl rectangle evaluated at once, then one lane follows the precomputed moves,
@@ -292,8 +292,8 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
  *   host  sr_recognize_batch with at most 256 KB of captures: pinned staging, results written to pinned host memory.
  * Same results bit for bit (tests run the DTW / VAD / recognition cases in every mode).  One 16 000-sample capture against
  * 80 slots: 242 us -> 66 us per spch_recg call on an otherwise idle MI355X (profiles/, latency block of bench.py).
- * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = the DTW form whenever the rectangle fits, whatever
- * the launch size. */
+ * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = always (the DTW form whenever the rectangle fits),
+ * whatever the launch size: for tests and measurements. */
 int sr_set_small_launch(sr_engine *h, int mode);
 int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);

@@ -89,6 +89,8 @@ struct DevBuf {
 
 using namespace sr;
 
+// launch sizes below which VAD / the frame kernel take their small-launch forms (captures; work items of 64 frames)
+static constexpr uint32_t kVadWideBelow = 1024, kMfccSmallBelow = 256;  // measured crossovers ~2 000 captures / ~256 items (RESULTS.md)
 // utterances of one call whose slot scan k_dtw_cells can do itself (one counter each); beyond that k_argmin runs as usual
 static constexpr uint32_t kPairCounters = 65536;
 
@@ -695,7 +697,7 @@ static VadArgs vad_args(const sr_engine *h, const uint16_t *pcm, uint64_t stride
                         sr_vad_rec *vad, const sr_atap *atap_in = nullptr, uint64_t *dbg = nullptr)
 {
     // fewer captures than CUs: a workgroup of four waves per capture instead of one wave (k_vad_wide; same records)
-    const uint32_t wide = (h->small_launch != 1 && B < 256) ? 1u : 0u;
+    const uint32_t wide = (h->small_launch == 2 || (h->small_launch == 0 && B < kVadWideBelow)) ? 1u : 0u;
     return VadArgs{pcm, stride, buf_len, noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, vad, atap_in, dbg,
                    h->frame_len, h->v_durmin, h->s_durmax, wide};
 }
@@ -727,7 +729,7 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.small_tiles = 0;
     // Fewer work items than CUs (a handful of captures: spch_recg, get_mfcc): the frame kernel's small-launch form, 8 frames per
     // workgroup instead of 64 -- a wave's frames are a serial chain, and nothing else would fill the chip.  Same arithmetic.
-    if (h->small_launch != 1 && h->mfcc_tile_small < h->mfcc_tile && (uint64_t)B * a.tiles < 256) {
+    if (h->mfcc_tile_small < h->mfcc_tile && (h->small_launch == 2 || (h->small_launch == 0 && (uint64_t)B * a.tiles < kMfccSmallBelow))) {
         a.tiles = (h->cfg.max_frames + h->mfcc_tile_small - 1) / h->mfcc_tile_small;
         a.small_tiles = 1;
     }

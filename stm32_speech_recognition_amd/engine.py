@@ -282,8 +282,9 @@ class Engine:
         self._check(self.L.sr_set_dp_lanes(self.h, C.c_uint32(lanes)))
 
     def set_small_launch(self, mode=0):
-        """DTW of launches with few pairs: 0 automatic (one workgroup per pair up to 1024 pairs), 1 never, 2 whenever the
-        in x mdl rectangle fits a workgroup's LDS.  Same scores in every mode."""
+        """Small-launch forms of the kernels (four waves per capture in VAD, 8-frame workgroups in the frame kernel, one
+        workgroup per DTW pair + in-kernel slot scan, pinned host staging): 0 automatic by launch size, 1 never, 2 always
+        (DTW: whenever the in x mdl rectangle fits a workgroup's LDS).  Same results in every mode."""
         self._check(self.L.sr_set_small_launch(self.h, C.c_int(mode)))
 
     def dtw_dp_dev(self, mfcc, scores, in_frames=None, vad=None, stream=None):
