@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
                 const Row16 ir = lds_row(s_in + ix * kRowWords);  // same address in every lane: broadcast
                 const int x = (int)ix + 1;
                 // (the start point (1, 1) is never a candidate: every candidate has x + 1 >= 2 or y + 1 >= 2)
-                const bool inside = (lb_of(x) <= y) & (y < ub1_of(x));
+                const bool inside = lb_of(x) <= y && y < ub1_of(x);
                 return inside ? dis_rows(md, ir) : SR_DIS_ERR;
             };
             uint32_t e_prev = entry(p0);

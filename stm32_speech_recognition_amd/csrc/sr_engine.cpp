@@ -134,6 +134,7 @@ struct sr_engine {
     // straight into pinned host memory -- one stream synchronisation per call instead of a blocking copy each way
     void *pin_buf = nullptr;
     size_t pin_cap = 0;
+    bool pin_failed = false;
     std::vector<hipEvent_t> ev_chunk;
     // device-resident pipeline (sr_recognize_batch_dev): the batch is cut into chunks that run on a few internal
     // streams, forked from and joined back to the caller's stream, so that the kernels of different chunks overlap
@@ -956,17 +957,25 @@ int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_
 // stream synchronisation per call instead of a blocking copy in each direction.
 static constexpr size_t kPinUpload = 256 * 1024, kPinMaxB = 256, kPinRes = kPinUpload, kPinRecs = kPinRes + kPinMaxB * sizeof(sr_result),
                         kPinMfcc = kPinRecs + kPinMaxB * sizeof(sr_vad_rec), kPinMfccBytes = 512 * 1024, kPinTotal = kPinMfcc + kPinMfccBytes;
-static int ensure_pin(sr_engine *h)
+// false = no pinned area on this host (allocation refused: the callers keep their blocking copies)
+static bool ensure_pin(sr_engine *h)
 {
     if (h->pin_cap < kPinTotal) {
-        if (h->pin_buf) (void)hipHostFree(h->pin_buf);
-        h->pin_buf = nullptr;
-        h->pin_cap = 0;
-        HIP_TRY(hipHostMalloc(&h->pin_buf, kPinTotal, hipHostMallocMapped));
+        if (h->pin_failed) return false;
+        if (hipHostMalloc(&h->pin_buf, kPinTotal, hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            h->pin_buf = nullptr;
+            h->pin_failed = true;
+            return false;
+        }
         h->pin_cap = kPinTotal;
     }
-    if (!h->st_comp) HIP_TRY(hipStreamCreateWithFlags(&h->st_comp, hipStreamNonBlocking));
-    return SR_OK;
+    if (!h->st_comp && hipStreamCreateWithFlags(&h->st_comp, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        h->st_comp = nullptr;
+        return false;
+    }
+    return true;
 }
 // rows of buf_len samples into the staging area at the device pitch ds (samples), the pad zeroed
 static void stage_rows(uint8_t *stage, const uint8_t *src, uint64_t src_pitch, uint64_t row_bytes, uint64_t ds, uint32_t B)
@@ -1017,8 +1026,7 @@ static int recognize_host(sr_engine *h, const void *pcm, uint64_t row_stride, bo
     const uint8_t *src = (const uint8_t *)pcm;
     // A few captures (spch_recg's one): two blocking copies cost more than the kernels.  The rows go through a pinned staging
     // area, the result records are written by the kernel into pinned host memory, and the host waits once.
-    if (!packed && !h->profiling && h->small_launch != 1 && (uint64_t)B * ds * 2 <= kPinUpload && B <= kPinMaxB) {
-        if ((rc = ensure_pin(h))) return rc;
+    if (!packed && !h->profiling && h->small_launch != 1 && (uint64_t)B * ds * 2 <= kPinUpload && B <= kPinMaxB && ensure_pin(h)) {
         const size_t res_off = kPinRes;
         uint8_t *stage = (uint8_t *)h->pin_buf;
         stage_rows(stage, src, src_pitch, src_row_bytes, ds, B);
@@ -1200,9 +1208,8 @@ int sr_mfcc_batch_status(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride,
     uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
     const size_t mbytes = (size_t)B * h->cfg.max_frames * h->nc * 2;
     int rc;
-    if (h->small_launch != 1 && B <= kPinMaxB && (uint64_t)B * ds * 2 <= kPinUpload && mbytes <= kPinMfccBytes) {
+    if (h->small_launch != 1 && B <= kPinMaxB && (uint64_t)B * ds * 2 <= kPinUpload && mbytes <= kPinMfccBytes && ensure_pin(h)) {
         // a few segments (get_mfcc: one): through the pinned area, one synchronisation (see ensure_pin)
-        if ((rc = ensure_pin(h))) return rc;
         if ((rc = h->s_pcm.reserve((size_t)B * ds))) return rc;
         if ((rc = h->s_vad.reserve(B))) return rc;
         if ((rc = h->s_mfcc.reserve(mbytes / 2))) return rc;
