@@ -16,7 +16,8 @@
 namespace sr {
 namespace cells {
 constexpr uint32_t kThreads = 1024;
-constexpr uint32_t kRowWords = 9;  // 8 packed coefficient pairs + the squared norm; odd stride: lanes on consecutive rows, distinct banks
+constexpr uint32_t kRowWords = 9;  // template rows: 8 packed coefficient pairs + the squared norm; odd stride: lanes on consecutive rows, distinct banks
+constexpr uint32_t kInWords = 12;  // input rows: the same nine words at a 48-byte stride (every lane reads the SAME row: three wide broadcast reads)
 // word of a point = what one or two steps of the walk from there add up to:
 //   bits 0-16  the cost (roots of the smallest admissible candidates, each at most 65 535)
 //   bits 17-18 how many of the steps had all three candidates outside (each costs dis_err = 2^32 - 1, DTW.C:152-164)
@@ -29,42 +30,69 @@ struct Row16 {
     uint32_t w[8];
     uint32_t n;
 };
-// a feature row of nc <= 16 s16 (2-byte aligned when nc is odd) as packed pairs, zero-padded: the pad adds nothing to
-// get_dis' sum of squares (DTW.C:45-62)
+// a feature row of nc <= 16 s16 as packed pairs, zero-padded (the pad adds nothing to get_dis' sum of squares, DTW.C:45-62),
+// + its squared norm.  12-coefficient rows are 24 bytes and 8-byte aligned (three wide loads); other widths are fetched
+// coefficient by coefficient (rows of an odd number of s16 are only 2-byte aligned).
 __device__ __forceinline__ void stage_row(uint32_t *dst, const int16_t *p, uint32_t nc)
 {
+    uint32_t w[8];
+    if (nc == (uint32_t)kCoef) {
+        const u32x2 *q = (const u32x2 *)p;
+        const u32x2 q0 = q[0], q1 = q[1], q2 = q[2];
+        w[0] = q0.x, w[1] = q0.y, w[2] = q1.x, w[3] = q1.y, w[4] = q2.x, w[5] = q2.y, w[6] = 0, w[7] = 0;
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t lo = (2 * i < nc) ? (uint32_t)(uint16_t)p[2 * i] : 0u, hi = (2 * i + 1 < nc) ? (uint32_t)(uint16_t)p[2 * i + 1] : 0u;
+            w[i] = lo | (hi << 16);
+        }
+    }
     int acc = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 8; i++) {
-        const uint32_t lo = (2 * i < nc) ? (uint32_t)(uint16_t)p[2 * i] : 0u, hi = (2 * i + 1 < nc) ? (uint32_t)(uint16_t)p[2 * i + 1] : 0u;
-        const uint32_t w = lo | (hi << 16);
-        dst[i] = w;
-        acc = sdot2(w, w, acc);
+        dst[i] = w[i];
+        acc = sdot2(w[i], w[i], acc);
     }
     dst[8] = (uint32_t)acc;
 }
+template <int kWords>
 __device__ __forceinline__ Row16 lds_row(const uint32_t *p)
 {
     Row16 r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.w[i] = p[i];
+    for (int i = 0; i < 8; i++) r.w[i] = i < kWords ? p[i] : 0u;
     r.n = p[8];
     return r;
 }
-// get_dis (DTW.C:45-62): sum (a-b)^2 in u32 wrap = |a|^2 + |b|^2 - 2 a.b in the same ring, then (u32)sqrtf
+// an input row (48-byte stride, 16-byte aligned): wide reads
+template <int kWords>
+__device__ __forceinline__ Row16 lds_in_row(const uint32_t *p)
+{
+    const u32x4 *q = (const u32x4 *)p;
+    const u32x4 a = q[0], b = q[1];
+    Row16 r;
+    r.w[0] = a.x, r.w[1] = a.y, r.w[2] = a.z, r.w[3] = a.w, r.w[4] = b.x, r.w[5] = b.y;
+    r.w[6] = kWords > 6 ? b.z : 0u, r.w[7] = kWords > 6 ? b.w : 0u;
+    r.n = p[8];
+    return r;
+}
+// get_dis (DTW.C:45-62): sum (a-b)^2 in u32 wrap = |a|^2 + |b|^2 - 2 a.b in the same ring, then (u32)sqrtf.
+// kWords = 6: feature rows of at most 12 coefficients (words 6 and 7 are zero padding)
+template <int kWords>
 __device__ __forceinline__ uint32_t dis_rows(const Row16 &a, const Row16 &b)
 {
     int dot = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) dot = sdot2(a.w[i], b.w[i], dot);
+    for (int i = 0; i < kWords; i++) dot = sdot2(a.w[i], b.w[i], dot);
     return cvt_u32(sqrt_rn_int((float)(a.n + b.n - 2u * (uint32_t)dot)));
 }
 }  // namespace cells
 
 size_t dtw_cells_lds(uint32_t max_frames, uint32_t tpl_rows)
 {
-    // rows 0 .. n of both sequences + one word per point (px, py), px < in_n - 1, py < mdl_n - 1 (at least one point)
-    return ((size_t)(max_frames + tpl_rows) * cells::kRowWords + (size_t)max_frames * tpl_rows) * sizeof(uint32_t);
+    // every allocated row of both sequences (staged before the frame counts are known) + one word per point (px, py),
+    // px < in_n - 1, py < mdl_n - 1 (at least one point)
+    return ((size_t)max_frames * cells::kInWords + (size_t)tpl_rows * cells::kRowWords + (size_t)max_frames * tpl_rows) * sizeof(uint32_t);
 }
 bool dtw_cells_fits(const DtwArgs &a)
 {
@@ -74,11 +102,38 @@ bool dtw_cells_fits(const DtwArgs &a)
            dtw_cells_lds(a.max_frames, a.tpl_rows) <= 150 * 1024;
 }
 
+#ifdef SR_CELLS_TIMING
+// development build only (-DSR_CELLS_TIMING): s_memtime at the phase boundaries of the workgroup of pair (0, 0)
+__device__ unsigned long long g_cells_t[8];
+extern "C" void sr_debug_cells_timing(unsigned long long *out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cells_t), sizeof(g_cells_t));
+}
+#define CELLS_T(i)                                                                        \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_cells_t[i] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CELLS_T(i) ((void)0)
+#endif
+template <int kWords>
 __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, uint32_t b0)
 {
+    CELLS_T(0);
     using namespace cells;
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     const uint32_t k = blockIdx.x, b = b0 + blockIdx.y, nc = a.n_coef, tid = threadIdx.x;
+    // every allocated row of the pair goes to LDS first -- before the frame counts have arrived, so that the two round trips
+    // to memory (the records, the rows) overlap
+    uint32_t *s_in = sm, *s_md = s_in + a.max_frames * kInWords, *s_pt = s_md + a.tpl_rows * kRowWords;
+    {
+        const int16_t *in = a.mfcc + (size_t)b * a.max_frames * nc, *mdl = a.tpl + (size_t)k * a.tpl_stride;
+        for (uint32_t r = tid; r < a.max_frames + a.tpl_rows; r += kThreads) {
+            if (r < a.max_frames) stage_row(s_in + r * kInWords, in + (size_t)r * nc, nc);
+            else stage_row(s_md + (r - a.max_frames) * kRowWords, mdl + (size_t)(r - a.max_frames) * nc, nc);
+        }
+    }
     uint32_t in_n, ok;
     if (a.in_frames) {
         in_n = a.in_frames[b];
@@ -88,21 +143,17 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
         ok = a.vad[b].status == SR_ST_OK && in_n != 0;
     }
     const uint32_t mdl_n = a.tpl_frames[k];
-    const uint32_t lane = tid & 63, wv = tid >> 6;
+    // (the wave index as a scalar: row ranges, loop counters and the column bounds of dtw_limit stay on the scalar unit)
+    const uint32_t lane = tid & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     uint32_t score = SR_DIS_ERR;
+    __syncthreads();
     // main.c:283, DTW.C:133-137; counts beyond the allocation (never produced by this library) are not walked
     if (ok && a.tpl_valid[k] && !(in_n > mdl_n * 2 || 2 * in_n < mdl_n || in_n > a.max_frames || mdl_n >= a.tpl_rows)) {  // workgroup-uniform
         // rows the walk can touch: x + 1 <= max(in_n, 2), y + 1 <= max(mdl_n, 2) (1-based; row 1 of a 1-frame sequence is the
         // slack row the reference's do-while reads, DTW.C:150-154)
         const uint32_t NX = in_n > 1 ? in_n : 2, NY = mdl_n > 1 ? mdl_n : 2;
         const uint32_t MX = NX - 1, MY = NY - 1;  // points the walk can stand on: px < MX, py < MY (0-based)
-        uint32_t *s_in = sm, *s_md = s_in + NX * kRowWords, *s_pt = s_md + NY * kRowWords;
-        const int16_t *in = a.mfcc + (size_t)b * a.max_frames * nc, *mdl = a.tpl + (size_t)k * a.tpl_stride;
-        for (uint32_t r = tid; r < NX + NY; r += kThreads) {
-            if (r < NX) stage_row(s_in + r * kRowWords, in + (size_t)r * nc, nc);
-            else stage_row(s_md + (r - NX) * kRowWords, mdl + (size_t)(r - NX) * nc, nc);
-        }
-        __syncthreads();
+        CELLS_T(1);  // rows staged
         const int X1 = (int)(((2 * (int)mdl_n - (int)in_n) / 3) & 0xFFFF);  // DTW.C:141-142 (u16 statics)
         const int X2 = (int)(((4 * (int)in_n - 2 * (int)mdl_n) / 3) & 0xFFFF);
         // dtw_limit (DTW.C:76-109) as an interval per column, lb(x) <= y < ub1(x) (see k_dtw_lds; every length pair checked point
@@ -125,14 +176,14 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
             const uint32_t c = cb * 63 + lane;  // column of E = template row; the lane's points are (ix - 1, c - 1)
             if (p0 >= p1) continue;
             const bool col = c <= MY;
-            const Row16 md = lds_row(s_md + (col ? c : 0u) * kRowWords);
+            const Row16 md = lds_row<kWords>(s_md + (col ? c : 0u) * kRowWords);
             const int y = (int)c + 1;  // 1-based y of the candidates in column c
             auto entry = [&](uint32_t ix) {
-                const Row16 ir = lds_row(s_in + ix * kRowWords);  // same address in every lane: broadcast
+                const Row16 ir = lds_in_row<kWords>(s_in + ix * kInWords);  // same address in every lane: broadcast
                 const int x = (int)ix + 1;
                 // (the start point (1, 1) is never a candidate: every candidate has x + 1 >= 2 or y + 1 >= 2)
                 const bool inside = lb_of(x) <= y && y < ub1_of(x);
-                return inside ? dis_rows(md, ir) : SR_DIS_ERR;
+                return inside ? dis_rows<kWords>(md, ir) : SR_DIS_ERR;
             };
             uint32_t e_prev = entry(p0);
             for (uint32_t ix = p0 + 1; ix <= p1; ix++) {
@@ -153,6 +204,7 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
             }
         }
         __syncthreads();
+        CELLS_T(2);  // points
         // ---- two steps per word: every point absorbs the point its step leads to (all reads, a barrier, all writes: in place).
         // The walk below is a chain of dependent LDS reads, ~110 cycles each; this halves it for one more pass over the points.
         const uint32_t npts = MX * MY;
@@ -181,9 +233,10 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
             }
             __syncthreads();
         }
+        CELLS_T(3);  // pair pass
         if (tid == 0) {
             // ---- the walk: DTW.C:146-191 as a chase through the points ----
-            uint32_t dis = dis_rows(lds_row(s_in), lds_row(s_md));  // DTW.C:146
+            uint32_t dis = dis_rows<kWords>(lds_in_row<kWords>(s_in), lds_row<kWords>(s_md));  // DTW.C:146
             uint32_t step = 1, at = 0, w;
             do {
                 w = s_pt[at];
@@ -195,6 +248,7 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
             score = dis / step;  // DTW.C:191
         }
     }
+    CELLS_T(4);  // walk
     if (wv != 0) return;
     uint32_t *sc = a.scores + (size_t)b * a.K;
     if (lane == 0) __hip_atomic_store(sc + k, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -236,6 +290,7 @@ __global__ void __launch_bounds__(cells::kThreads) k_dtw_cells(const DtwArgs a, 
         a.results[b] = r;
         __hip_atomic_store(a.pair_count + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    CELLS_T(5);  // slot scan (only if this pair was the last one)
 }
 
 void launch_dtw_cells(const DtwArgs &a, hipStream_t s)
@@ -244,7 +299,8 @@ void launch_dtw_cells(const DtwArgs &a, hipStream_t s)
     const size_t lds = dtw_cells_lds(a.max_frames, a.tpl_rows);
     for (uint32_t b0 = 0; b0 < a.B; b0 += 65535) {  // utterances are the grid's second dimension
         const uint32_t nb = a.B - b0 < 65535 ? a.B - b0 : 65535;
-        hipLaunchKernelGGL(k_dtw_cells, dim3(a.K, nb), dim3(cells::kThreads), lds, s, a, b0);
+        if (a.n_coef <= (uint32_t)kCoef) hipLaunchKernelGGL(k_dtw_cells<6>, dim3(a.K, nb), dim3(cells::kThreads), lds, s, a, b0);
+        else hipLaunchKernelGGL(k_dtw_cells<8>, dim3(a.K, nb), dim3(cells::kThreads), lds, s, a, b0);
     }
 }
 
