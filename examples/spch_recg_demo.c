@@ -11,6 +11,7 @@
  *   /tmp/spch_recg_demo store.bin capture.bin        (store: n x 4096 bytes, capture: 16000 x u16)
  */
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -102,5 +103,18 @@ int main(int argc, char **argv)
            label ? (char *)label : "(null)", d2, res.best_tpl, res.min_dis, res.status, res.frm_num);
     if ((slot >= 0) != (label != NULL) || d1 != d2 || d2 != res.min_dis || (slot >= 0 && (unsigned)slot != res.best_tpl))
         return 1;
+    /* (4) what one spch_recg call costs once the engine is warm (plain C, no interpreter in the loop) */
+    {
+        struct timespec t0, t1;
+        uint32_t d3 = 0;
+        int i, n = 200;
+        for (i = 0; i < 20; i++) (void)spch_recg(VcBuf, &d3);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (i = 0; i < n; i++) (void)spch_recg(VcBuf, &d3);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        printf("spch_recg: %.1f us per call (mean of %d, one call in flight)\n",
+               ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / 1e3 / n, n);
+        if (d3 != d2) return 1;
+    }
     return 0;
 }

@@ -1710,6 +1710,8 @@ def test_c_demo_reference_call_pattern(golden, tmp_path):
                              timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert f"slot={golden['recg_best'][b]} dis={golden['recg_dis'][b]} " in out.stdout, out.stdout
+        assert "us per call" in out.stdout  # the demo's timing loop ran (and gave the same distance every time)
+        print(out.stdout.strip().splitlines()[-1])
     np.full(16000, 2048, np.uint16).tofile(str(tmp_path / "cap.bin"))  # silence: NULL + dis_err everywhere
     out = subprocess.run([exe, str(tmp_path / "store.bin"), str(tmp_path / "cap.bin")], capture_output=True, text=True,
                          timeout=120)
