@@ -285,7 +285,7 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
  * frames, dtw's walk), and a few of them leave the GPU idle.  The engine then spends the idle width instead:
  *   VAD   fewer than 1024 captures: a workgroup of four waves per capture (k_vad_wide) instead of one wave;
  *   MFCC  fewer than 256 work items: 8 frames per workgroup instead of 64 (reference front end);
- *   DTW   up to 2048 pairs per launch (1024 per workgroup that fits a CU's LDS): every pair gets its own workgroup
+ *   DTW   up to 2560 pairs per launch (1280 per workgroup that fits a CU's LDS): every pair gets its own workgroup
  *         (k_dtw_cells: all points of the in x mdl rectangle evaluated at once, then one lane follows the precomputed moves,
  *         and the last pair of an utterance does the slot scan), provided the rectangle fits a workgroup's LDS
  *         (max_frames x (longest template + 1) <= ~36 000 points and at most 1022 template frames; the firmware's 119 x 119 does);

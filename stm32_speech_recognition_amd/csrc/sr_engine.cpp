@@ -793,12 +793,13 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
 // Measured on 110-frame captures against 80 slots of up to 119 frames (66 KB of LDS per pair, two workgroups per CU;
 // profiles/experiments/RESULTS.md): 80 / 320 / 640 / 960 / 1 280 / 1 920 / 2 560 / 3 840 pairs take 25 / 30 / 45 / 54 / 67 / 92 /
 // 113 / 160 us with one workgroup per pair against 123-136 us for the batch kernel at any of these sizes.  The automatic
-// mode stops at four rounds of resident workgroups: 1 024 pairs per workgroup that fits a CU's LDS (at most 4 counted).
+// mode stops at five rounds of resident workgroups: 1 280 pairs per workgroup that fits a CU's LDS (at most 4 counted) --
+// 2 560 pairs here, where a whole call still wins (profiles/r04_small_launch_sweep.json: B = 32, 142 against 166 us).
 static uint64_t small_launch_pairs(const DtwArgs &a)
 {
     const size_t lds = (dtw_cells_lds(a.max_frames, a.tpl_rows) + 1279) / 1280 * 1280;  // LDS granule of gfx950
     const uint64_t per_cu = std::min<uint64_t>(4, std::max<uint64_t>(1, 160 * 1024 / lds));
-    return 1024 * per_cu;
+    return 1280 * per_cu;
 }
 // returns true when the slot scan (argmin) has been done as well: k_dtw_cells with result records asked for and the utterances
 // b0 .. b0 + B of the call within the counters
