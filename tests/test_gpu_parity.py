@@ -561,6 +561,36 @@ def test_small_launch_dtw_matches_oracle(seed):
     eng.close()
 
 
+def test_small_launch_forms_are_taken(golden):
+    """one capture against an 80-slot store at the firmware's shapes: the automatic mode must pick the small-launch kernel forms
+    (k_vad_wide, k_mfcc<2>, k_dtw_cells + in-kernel slot scan), which shows as at least 1.5x fewer microseconds per call than
+    with them switched off (measured 55 vs 214) -- a silent fallback to the batch kernels would pass every parity test"""
+    import time
+    from stm32_speech_recognition_amd import Engine
+    eng = Engine(max_frames=119, device=0)
+    bank = synth.word_bank(25)
+    rng = np.random.default_rng(4)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(80) % 25, rng.integers(70, 120, 80), seed=8, bank=bank, S=16000))
+    store, st = eng.train_store(tp, np.arange(80), n_slots=80)
+    eng.set_templates_store(store)
+    d = synth.make_utterances([3], [110], seed=9, bank=bank, S=16000, device=torch.device("cuda", 0))
+    o = eng.alloc_outputs(1, "cuda:0", mfcc=False, vad=False)
+    med, res = {}, {}
+    for mode in (1, 0):
+        eng.set_small_launch(mode)
+        ts = []
+        for i in range(40):
+            t0 = time.perf_counter()
+            eng.recognize_dev(d, o)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        med[mode] = float(np.median(ts[10:]))
+        res[mode] = o["results"].cpu().numpy().copy()
+    assert np.array_equal(res[0], res[1])
+    assert med[0] * 1.5 < med[1], med
+    eng.close()
+
+
 @pytest.mark.parametrize("K", [513, 700, 1500, 2050])
 def test_dtw_large_template_stores_match_oracle(K):
     """more templates than one workgroup of the staged DTW kernel holds (1024 lanes): the length-sorted store is walked in
