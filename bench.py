@@ -479,7 +479,7 @@ def latency_block(local_rank, n_utt=64):
       dtw slot scan  main.c:279-291's loop: 80 dtw() calls for one input record (the symbol scores the record against every
                      cached model in ONE launch, the other 79 calls are look-ups)
       sr_recognize_batch_dev at B = 1, 16, 256 on device-resident captures, synchronised after every call
-    Launches this small take the engine's small-launch forms (k_vad_wide, 8-frame tiles, k_dtw_cells; sr_set_small_launch);
+    Launches this small take the engine's small-launch forms (k_vad_wide, 4-frame tiles, k_dtw_cells; sr_set_small_launch);
     `*_batch_kernels_us` is the same call with them switched off."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol

@@ -10,9 +10,10 @@ namespace sr {
 // ------------------------------------------------------------------------------------------------
 constexpr int kMfccWaves = 4;       // waves per workgroup
 // consecutive frames one wave turns into MFCCs per work item: 16 in the batch form (the lane constants and tables a workgroup
-// sets up are amortised over 64 frames), 2 in the small-launch form (one capture = 110 frames is 14 workgroups instead of 2:
-// a wave's frames are a serial chain of ~1.5 us each, and with a handful of captures nothing else fills the chip)
-constexpr int kFramesPerWave = 16, kFramesPerWaveSmall = 2;
+// sets up are amortised over 64 frames), 1 in the small-launch form (one capture = 110 frames is 28 workgroups instead of 2:
+// a wave's frames are a serial chain of ~1.5 us each, and with a handful of captures nothing else fills the chip;
+// 2 frames per wave: 8.1 instead of 7 us for one capture, 19 instead of 22 us for 64)
+constexpr int kFramesPerWave = 16, kFramesPerWaveSmall = 1;
 // per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
 // rows of the filterbank outputs and of the DCT tables are kMelPad = 25 words apart: in the DCT the lanes of a wave read
 // 6 different frames x 12 different coefficients rows at the same column, and a stride of 24 folds those onto 4 banks

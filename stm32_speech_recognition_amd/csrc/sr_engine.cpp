@@ -728,7 +728,7 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.mfcc = d_mfcc;
     a.tiles = (h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile;
     a.small_tiles = 0;
-    // Fewer work items than CUs (a handful of captures: spch_recg, get_mfcc): the frame kernel's small-launch form, 8 frames per
+    // Fewer work items than CUs (a handful of captures: spch_recg, get_mfcc): the frame kernel's small-launch form, 4 frames per
     // workgroup instead of 64 -- a wave's frames are a serial chain, and nothing else would fill the chip.  Same arithmetic.
     if (h->mfcc_tile_small < h->mfcc_tile && (h->small_launch == 2 || (h->small_launch == 0 && (uint64_t)B * a.tiles < kMfccSmallBelow))) {
         a.tiles = (h->cfg.max_frames + h->mfcc_tile_small - 1) / h->mfcc_tile_small;

@@ -282,7 +282,7 @@ class Engine:
         self._check(self.L.sr_set_dp_lanes(self.h, C.c_uint32(lanes)))
 
     def set_small_launch(self, mode=0):
-        """Small-launch forms of the kernels (four waves per capture in VAD, 8-frame workgroups in the frame kernel, one
+        """Small-launch forms of the kernels (four waves per capture in VAD, 4-frame workgroups in the frame kernel, one
         workgroup per DTW pair + in-kernel slot scan, pinned host staging): 0 automatic by launch size, 1 never, 2 always
         (DTW: whenever the in x mdl rectangle fits a workgroup's LDS).  Same results in every mode."""
         self._check(self.L.sr_set_small_launch(self.h, C.c_int(mode)))

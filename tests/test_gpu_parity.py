@@ -563,7 +563,7 @@ def test_small_launch_dtw_matches_oracle(seed):
 
 def test_small_launch_forms_are_taken(golden):
     """one capture against an 80-slot store at the firmware's shapes: the automatic mode must pick the small-launch kernel forms
-    (k_vad_wide, k_mfcc<2>, k_dtw_cells + in-kernel slot scan), which shows as at least 1.5x fewer microseconds per call than
+    (k_vad_wide, k_mfcc<1>, k_dtw_cells + in-kernel slot scan), which shows as at least 1.5x fewer microseconds per call than
     with them switched off (measured 55 vs 214) -- a silent fallback to the batch kernels would pass every parity test"""
     import time
     from stm32_speech_recognition_amd import Engine
