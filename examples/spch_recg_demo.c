@@ -115,6 +115,14 @@ int main(int argc, char **argv)
         printf("spch_recg: %.1f us per call (mean of %d, one call in flight)\n",
                ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / 1e3 / n, n);
         if (d3 != d2) return 1;
+        /* ... and the reference's own sequence: noise_atap, VAD, get_mfcc, dtw per slot (main.c:258-291) */
+        for (i = 0; i < 20; i++) (void)recognise(VcBuf, store, n_slots, &d3);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (i = 0; i < n; i++) (void)recognise(VcBuf, store, n_slots, &d3);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        printf("noise_atap + VAD + get_mfcc + %u x dtw: %.1f us per capture\n", n_slots,
+               ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / 1e3 / n);
+        if (d3 != d1) return 1;
     }
     return 0;
 }

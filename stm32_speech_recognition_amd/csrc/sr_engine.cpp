@@ -953,11 +953,14 @@ int sr_recognize_segments_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_
                                 sr_result *results, uint32_t *scores, sr_vad_rec *vad);
 
 // ---- host-buffer wrappers (stage through HBM) --------------------------------------------------------
-// Pinned host area of the small host-buffer calls (spch_recg / get_mfcc: one capture): captures staged for the upload | result
-// records the kernel writes directly | per-utterance records for the frame kernel | feature rows on their way back.  One
-// stream synchronisation per call instead of a blocking copy in each direction.
-static constexpr size_t kPinUpload = 256 * 1024, kPinMaxB = 256, kPinRes = kPinUpload, kPinRecs = kPinRes + kPinMaxB * sizeof(sr_result),
-                        kPinMfcc = kPinRecs + kPinMaxB * sizeof(sr_vad_rec), kPinMfccBytes = 512 * 1024, kPinTotal = kPinMfcc + kPinMfccBytes;
+// Pinned host area of the small host-buffer calls (spch_recg / get_mfcc / VAD / dtw: one capture, one record): what goes up
+// is staged in its first part, what comes back lands in its second part (result records are written there by the kernel
+// itself).  Everything is enqueued on one internal stream and the host waits ONCE per call, instead of one blocking copy per
+// buffer and direction.
+static constexpr size_t kPinUpload = 256 * 1024, kPinMaxB = 256;           // captures of one small call; utterances
+static constexpr size_t kPinUpBytes = kPinUpload + 64 * 1024;             // + records / frame counts / thresholds
+static constexpr size_t kPinDownBytes = 704 * 1024, kPinTotal = kPinUpBytes + kPinDownBytes;
+static constexpr size_t kPinMfccBytes = 512 * 1024;
 // false = no pinned area on this host (allocation refused: the callers keep their blocking copies)
 static bool ensure_pin(sr_engine *h)
 {
@@ -978,6 +981,53 @@ static bool ensure_pin(sr_engine *h)
     }
     return true;
 }
+// one small call: bump allocation in the two parts of the pinned area, asynchronous copies on the internal stream
+struct PinCall {
+    sr_engine *h;
+    uint8_t *base;
+    size_t up = 0, down = kPinUpBytes;
+    bool ok = true;
+    explicit PinCall(sr_engine *e) : h(e), base((uint8_t *)e->pin_buf) {}
+    hipStream_t stream() const { return h->st_comp; }
+    uint8_t *stage(size_t bytes)  // room in the upload part (callers check the sizes beforehand with pin_fits)
+    {
+        uint8_t *p = base + up;
+        up += (bytes + 63) & ~(size_t)63;
+        return p;
+    }
+    void upload(void *dev, const void *src, size_t bytes)  // host buffer -> staging -> device
+    {
+        uint8_t *p = stage(bytes);
+        std::memcpy(p, src, bytes);
+        if (hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, h->st_comp) != hipSuccess) ok = false;
+    }
+    uint8_t *landing(size_t bytes)  // room in the download part
+    {
+        uint8_t *p = base + down;
+        down += (bytes + 63) & ~(size_t)63;
+        return p;
+    }
+    uint8_t *download(const void *dev, size_t bytes)
+    {
+        uint8_t *p = landing(bytes);
+        if (hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, h->st_comp) != hipSuccess) ok = false;
+        return p;
+    }
+    int finish()  // the one synchronisation of the call
+    {
+        const hipError_t e = hipStreamSynchronize(h->st_comp);
+        if (e != hipSuccess || !ok) {
+            (void)hipGetLastError();
+            return fail(SR_ERR_HIP, "small host call: copy / synchronisation failed");
+        }
+        return SR_OK;
+    }
+};
+static bool pin_fits(sr_engine *h, size_t up_bytes, size_t down_bytes, uint32_t n_up = 1, uint32_t n_down = 1)
+{
+    return h->small_launch != 1 && up_bytes + 64 * (size_t)n_up <= kPinUpBytes && down_bytes + 64 * (size_t)n_down <= kPinDownBytes &&
+           ensure_pin(h);
+}
 // rows of buf_len samples into the staging area at the device pitch ds (samples), the pad zeroed
 static void stage_rows(uint8_t *stage, const uint8_t *src, uint64_t src_pitch, uint64_t row_bytes, uint64_t ds, uint32_t B)
 {
@@ -985,6 +1035,18 @@ static void stage_rows(uint8_t *stage, const uint8_t *src, uint64_t src_pitch, u
         std::memcpy(stage + (size_t)b * ds * 2, src + (size_t)b * src_pitch, (size_t)row_bytes);
         if (ds * 2 > row_bytes) std::memset(stage + (size_t)b * ds * 2 + row_bytes, 0, (size_t)(ds * 2 - row_bytes));
     }
+}
+// captures of a small call: staged at the device pitch and sent on their way; false = not a small call (caller: stage_pcm)
+static bool pin_stage_pcm(sr_engine *h, PinCall &pc, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
+                          uint64_t *dev_stride, int *rc)
+{
+    const uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
+    if ((*rc = h->s_pcm.reserve((size_t)B * ds))) return false;
+    uint8_t *st = pc.stage((size_t)B * ds * 2);
+    stage_rows(st, (const uint8_t *)pcm, pcm_stride * 2, (uint64_t)buf_len * 2, ds, B);
+    if (hipMemcpyAsync(h->s_pcm.p, st, (size_t)B * ds * 2, hipMemcpyHostToDevice, h->st_comp) != hipSuccess) pc.ok = false;
+    *dev_stride = ds;
+    return true;
 }
 
 static int stage_pcm(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
@@ -1027,20 +1089,18 @@ static int recognize_host(sr_engine *h, const void *pcm, uint64_t row_stride, bo
     const uint8_t *src = (const uint8_t *)pcm;
     // A few captures (spch_recg's one): two blocking copies cost more than the kernels.  The rows go through a pinned staging
     // area, the result records are written by the kernel into pinned host memory, and the host waits once.
-    if (!packed && !h->profiling && h->small_launch != 1 && (uint64_t)B * ds * 2 <= kPinUpload && B <= kPinMaxB && ensure_pin(h)) {
-        const size_t res_off = kPinRes;
-        uint8_t *stage = (uint8_t *)h->pin_buf;
-        stage_rows(stage, src, src_pitch, src_row_bytes, ds, B);
+    if (!packed && !h->profiling && B <= kPinMaxB && pin_fits(h, (size_t)B * ds * 2, (size_t)B * sizeof(sr_result))) {
+        PinCall pc(h);
+        uint64_t ds2 = 0;
+        if (!pin_stage_pcm(h, pc, (const uint16_t *)pcm, row_stride, buf_len, B, &ds2, &rc)) return rc;
+        uint8_t *res_host = pc.landing((size_t)B * sizeof(sr_result));
         void *d_res = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&d_res, stage + res_off, 0));
-        HIP_TRY(hipMemcpyAsync(h->s_pcm.p, stage, (size_t)B * ds * 2, hipMemcpyHostToDevice, h->st_comp));
-        rc = sr_recognize_batch_dev(h, h->s_pcm.p, ds, buf_len, B, (sr_result *)d_res, h->s_scores.p, h->s_mfcc.p, h->s_vad.p, h->st_comp);
-        if (rc) {
-            (void)hipStreamSynchronize(h->st_comp);
-            return rc;
-        }
-        HIP_TRY(hipStreamSynchronize(h->st_comp));
-        std::memcpy(results, stage + res_off, (size_t)B * sizeof(sr_result));
+        HIP_TRY(hipHostGetDevicePointer(&d_res, res_host, 0));
+        rc = sr_recognize_batch_dev(h, h->s_pcm.p, ds, buf_len, B, (sr_result *)d_res, h->s_scores.p, h->s_mfcc.p, h->s_vad.p, pc.stream());
+        const int rcs = pc.finish();
+        if (rc) return rc;
+        if (rcs) return rcs;
+        std::memcpy(results, res_host, (size_t)B * sizeof(sr_result));
         if (scores) HIP_TRY(hipMemcpy(scores, h->s_scores.p, (size_t)B * h->K * 4, hipMemcpyDeviceToHost));
         if (mfcc) HIP_TRY(hipMemcpy(mfcc, h->s_mfcc.p, (size_t)B * h->cfg.max_frames * h->nc * 2, hipMemcpyDeviceToHost));
         if (vad) HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
@@ -1136,10 +1196,22 @@ int sr_vad_batch(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_
     if (B == 0) return SR_OK;
     if (buf_len > pcm_stride) return fail(SR_ERR_BAD_ARG, "buf_len exceeds pcm_stride");
     ENTER_DEVICE(h);
-    uint64_t ds = 0;
-    int rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
-    if (rc) return rc;
+    uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
+    int rc;
     if ((rc = h->s_vad.reserve(B))) return rc;
+    if (B <= kPinMaxB && pin_fits(h, (size_t)B * ds * 2, (size_t)B * sizeof(sr_vad_rec))) {  // a few captures: see PinCall
+        PinCall pc(h);
+        if (!pin_stage_pcm(h, pc, pcm, pcm_stride, buf_len, B, &ds, &rc)) return rc;
+        rc = sr_vad_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_vad.p, pc.stream());
+        const uint8_t *back = rc ? nullptr : pc.download(h->s_vad.p, (size_t)B * sizeof(sr_vad_rec));
+        const int rcs = pc.finish();
+        if (rc) return rc;
+        if (rcs) return rcs;
+        std::memcpy(vad, back, (size_t)B * sizeof(sr_vad_rec));
+        return SR_OK;
+    }
+    rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
+    if (rc) return rc;
     if ((rc = sr_vad_batch_dev(h, h->s_pcm.p, ds, buf_len, B, h->s_vad.p, nullptr))) return rc;
     HIP_TRY(hipMemcpy(vad, h->s_vad.p, (size_t)B * sizeof(sr_vad_rec), hipMemcpyDeviceToHost));
     return SR_OK;
@@ -1209,22 +1281,19 @@ int sr_mfcc_batch_status(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride,
     uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
     const size_t mbytes = (size_t)B * h->cfg.max_frames * h->nc * 2;
     int rc;
-    if (h->small_launch != 1 && B <= kPinMaxB && (uint64_t)B * ds * 2 <= kPinUpload && mbytes <= kPinMfccBytes && ensure_pin(h)) {
-        // a few segments (get_mfcc: one): through the pinned area, one synchronisation (see ensure_pin)
-        if ((rc = h->s_pcm.reserve((size_t)B * ds))) return rc;
+    if (B <= kPinMaxB && mbytes <= kPinMfccBytes && pin_fits(h, (size_t)B * (ds * 2 + sizeof(sr_vad_rec)), mbytes, 2, 1)) {
+        // a few segments (get_mfcc: one): through the pinned area, one synchronisation (see PinCall)
         if ((rc = h->s_vad.reserve(B))) return rc;
         if ((rc = h->s_mfcc.reserve(mbytes / 2))) return rc;
-        uint8_t *pin = (uint8_t *)h->pin_buf;
-        stage_rows(pin, (const uint8_t *)pcm, pcm_stride * 2, (uint64_t)buf_len * 2, ds, B);
-        std::memcpy(pin + kPinRecs, recs.data(), (size_t)B * sizeof(sr_vad_rec));
-        HIP_TRY(hipMemcpyAsync(h->s_pcm.p, pin, (size_t)B * ds * 2, hipMemcpyHostToDevice, h->st_comp));
-        HIP_TRY(hipMemcpyAsync(h->s_vad.p, pin + kPinRecs, (size_t)B * sizeof(sr_vad_rec), hipMemcpyHostToDevice, h->st_comp));
-        rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, B, h->s_vad.p, h->s_mfcc.p, h->st_comp);
-        if (!rc && hipMemcpyAsync(pin + kPinMfcc, h->s_mfcc.p, mbytes, hipMemcpyDeviceToHost, h->st_comp) != hipSuccess)
-            rc = fail(SR_ERR_HIP, "hipMemcpyAsync");
-        HIP_TRY(hipStreamSynchronize(h->st_comp));
+        PinCall pc(h);
+        if (!pin_stage_pcm(h, pc, pcm, pcm_stride, buf_len, B, &ds, &rc)) return rc;
+        pc.upload(h->s_vad.p, recs.data(), (size_t)B * sizeof(sr_vad_rec));
+        rc = sr_mfcc_batch_dev(h, h->s_pcm.p, ds, B, h->s_vad.p, h->s_mfcc.p, pc.stream());
+        const uint8_t *back = rc ? nullptr : pc.download(h->s_mfcc.p, mbytes);
+        const int rcs = pc.finish();
         if (rc) return rc;
-        std::memcpy(mfcc, pin + kPinMfcc, mbytes);
+        if (rcs) return rcs;
+        std::memcpy(mfcc, back, mbytes);
         return SR_OK;
     }
     rc = stage_pcm(h, pcm, pcm_stride, buf_len, B, &ds);
@@ -1300,6 +1369,22 @@ int sr_dtw_batch(sr_engine *h, const int16_t *in_mfcc, const uint32_t *in_frames
     if ((rc = h->s_u32a.reserve(B))) return rc;
     if ((rc = h->s_scores.reserve((size_t)B * h->K))) return rc;
     if ((rc = h->s_results.reserve(B))) return rc;
+    const size_t sc_bytes = (size_t)B * h->K * 4, res_bytes = results ? (size_t)B * sizeof(sr_result) : 0;
+    if (pin_fits(h, msz * 2 + (size_t)B * 4, sc_bytes + res_bytes, 2, 2)) {  // a few records (dtw(): one): see PinCall
+        PinCall pc(h);
+        pc.upload(h->s_mfcc.p, in_mfcc, msz * 2);
+        pc.upload(h->s_u32a.p, in_frames, (size_t)B * 4);
+        DtwArgs a = dtw_args(h, h->s_mfcc.p, nullptr, h->s_u32a.p, B, h->s_scores.p, h->s_results.p);
+        if (!launch_dtw_auto(h, a, 0, pc.stream())) launch_argmin(a, pc.stream());
+        const hipError_t le = hipGetLastError();
+        const uint8_t *sc_back = pc.download(h->s_scores.p, sc_bytes);
+        const uint8_t *res_back = results ? pc.download(h->s_results.p, res_bytes) : nullptr;
+        if ((rc = pc.finish())) return rc;
+        if (le != hipSuccess) return fail(SR_ERR_HIP, hipGetErrorString(le));
+        std::memcpy(scores, sc_back, sc_bytes);
+        if (results) std::memcpy(results, res_back, res_bytes);
+        return SR_OK;
+    }
     HIP_TRY(hipMemcpy(h->s_mfcc.p, in_mfcc, msz * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->s_u32a.p, in_frames, (size_t)B * 4, hipMemcpyHostToDevice));
     DtwArgs a = dtw_args(h, h->s_mfcc.p, nullptr, h->s_u32a.p, B, h->s_scores.p, h->s_results.p);
@@ -1489,11 +1574,25 @@ int engine_dtw_limit(sr_engine *h, uint16_t x, uint16_t y, int X1, int X2, int i
 int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, const sr_atap *atap, sr_vad_rec *rec)
 {
     ENTER_DEVICE(h);
-    uint64_t ds = 0;
-    int rc = stage_pcm(h, pcm, buf_len, buf_len, 1, &ds);
-    if (rc) return rc;
+    uint64_t ds = ((uint64_t)buf_len + 7) & ~7ull;
+    int rc;
     if ((rc = h->s_vad.reserve(1))) return rc;
     if ((rc = h->s_atap.reserve(1))) return rc;
+    if (pin_fits(h, (size_t)ds * 2 + sizeof(sr_atap), sizeof(sr_vad_rec), 2, 1)) {  // VAD(): one capture, see PinCall
+        PinCall pc(h);
+        if (!pin_stage_pcm(h, pc, pcm, buf_len, buf_len, 1, &ds, &rc)) return rc;
+        pc.upload(h->s_atap.p, atap, sizeof(sr_atap));
+        VadArgs a = vad_args(h, h->s_pcm.p, ds, buf_len, h->noise_len, 1, h->s_vad.p, h->s_atap.p);
+        launch_vad(a, pc.stream());
+        const hipError_t le = hipGetLastError();
+        const uint8_t *back = pc.download(h->s_vad.p, sizeof(sr_vad_rec));
+        if ((rc = pc.finish())) return rc;
+        if (le != hipSuccess) return fail(SR_ERR_HIP, hipGetErrorString(le));
+        std::memcpy(rec, back, sizeof(sr_vad_rec));
+        return SR_OK;
+    }
+    rc = stage_pcm(h, pcm, buf_len, buf_len, 1, &ds);
+    if (rc) return rc;
     HIP_TRY(hipMemcpy(h->s_atap.p, atap, sizeof(sr_atap), hipMemcpyHostToDevice));
     VadArgs a = vad_args(h, h->s_pcm.p, ds, buf_len, h->noise_len, 1, h->s_vad.p, h->s_atap.p);
     launch_vad(a, nullptr);
@@ -1507,10 +1606,23 @@ int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, co
 int engine_noise_atap(sr_engine *h, const uint16_t *noise, uint32_t n_len, sr_atap *out)
 {
     ENTER_DEVICE(h);
-    uint64_t ds = 0;
-    int rc = stage_pcm(h, noise, n_len, n_len, 1, &ds);
-    if (rc) return rc;
+    uint64_t ds = ((uint64_t)n_len + 7) & ~7ull;
+    int rc;
     if ((rc = h->s_vad.reserve(1))) return rc;
+    if (pin_fits(h, (size_t)ds * 2, sizeof(sr_vad_rec))) {  // noise_atap(): one noise head, see PinCall
+        PinCall pc(h);
+        if (!pin_stage_pcm(h, pc, noise, n_len, n_len, 1, &ds, &rc)) return rc;
+        VadArgs a = vad_args(h, h->s_pcm.p, ds, n_len, n_len, 1, h->s_vad.p);
+        launch_vad(a, pc.stream());
+        const hipError_t le = hipGetLastError();
+        const uint8_t *back = pc.download(h->s_vad.p, sizeof(sr_vad_rec));
+        if ((rc = pc.finish())) return rc;
+        if (le != hipSuccess) return fail(SR_ERR_HIP, hipGetErrorString(le));
+        *out = ((const sr_vad_rec *)back)->atap;
+        return SR_OK;
+    }
+    rc = stage_pcm(h, noise, n_len, n_len, 1, &ds);
+    if (rc) return rc;
     VadArgs a = vad_args(h, h->s_pcm.p, ds, n_len, n_len, 1, h->s_vad.p);
     launch_vad(a, nullptr);
     HIP_TRY(hipGetLastError());

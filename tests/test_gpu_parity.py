@@ -90,9 +90,12 @@ def test_direct_mfcc_edge_cases_match_golden(eng119, golden):
     """log(0) frames, s16 wrap after windowing, u32 wrap in the filterbank, full-range u16 codes"""
     dp, dmid, dm = golden["direct_pcm"], golden["direct_mid"], golden["direct_mfcc"]
     D, nfd = dm.shape[0], dm.shape[1]
-    n, m = eng119.mfcc(dp, np.ones(D, np.int32), np.full(D, 1 + 160 + 80 * (nfd - 1), np.int32), dmid)
-    assert (n == nfd).all()
-    assert np.array_equal(m[:, :nfd], dm)
+    for mode in (0, 1):  # through the pinned staging area / with blocking copies
+        eng119.set_small_launch(mode)
+        n, m = eng119.mfcc(dp, np.ones(D, np.int32), np.full(D, 1 + 160 + 80 * (nfd - 1), np.int32), dmid)
+        assert (n == nfd).all()
+        assert np.array_equal(m[:, :nfd], dm)
+    eng119.set_small_launch(0)
 
 
 def test_dtw_matches_golden(golden):
@@ -635,7 +638,22 @@ def test_log_step_table_covers_all_steps(eng119, oracle):
 
 
 # ----------------------------------------------------------------------------- reference-compatible symbols
-def test_compat_symbols_match_golden(golden, oracle):
+@pytest.fixture
+def compat_small_launch(request):
+    """the implicit engine of the scalar symbols with the small-launch forms on (0: pinned staging, k_vad_wide, ...) or off
+    (1: blocking copies, batch kernels)"""
+    import ctypes as C
+    from stm32_speech_recognition_amd.engine import load_library
+    L = load_library()
+    L.sr_compat_engine.restype = C.c_void_p
+    ce = C.c_void_p(L.sr_compat_engine())
+    assert L.sr_set_small_launch(ce, C.c_int(request.param)) == 0
+    yield request.param
+    L.sr_set_small_launch(ce, C.c_int(0))
+
+
+@pytest.mark.parametrize("compat_small_launch", [0, 1], indirect=True)
+def test_compat_symbols_match_golden(golden, oracle, compat_small_launch):
     from stm32_speech_recognition_amd import compat
     pcm = golden["pcm"][0]
     at = compat.atap_tag()
@@ -1740,8 +1758,8 @@ def test_c_demo_reference_call_pattern(golden, tmp_path):
                              timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert f"slot={golden['recg_best'][b]} dis={golden['recg_dis'][b]} " in out.stdout, out.stdout
-        assert "us per call" in out.stdout  # the demo's timing loop ran (and gave the same distance every time)
-        print(out.stdout.strip().splitlines()[-1])
+        assert "us per call" in out.stdout and "us per capture" in out.stdout  # the demo's timing loops ran (same distances every time)
+        print("\n".join(out.stdout.strip().splitlines()[-2:]))
     np.full(16000, 2048, np.uint16).tofile(str(tmp_path / "cap.bin"))  # silence: NULL + dis_err everywhere
     out = subprocess.run([exe, str(tmp_path / "store.bin"), str(tmp_path / "cap.bin")], capture_output=True, text=True,
                          timeout=120)
