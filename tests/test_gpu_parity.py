@@ -564,6 +564,46 @@ def test_small_launch_dtw_matches_oracle(seed):
     eng.close()
 
 
+def test_small_launch_soak():
+    """thousands of small calls in the automatic mode against one run of the batch kernels: random sub-batches of 1-24 captures
+    of random lengths, cut into chunks of 1 / 2 / 5 captures on three streams (several k_dtw_cells launches and their finished-
+    pair counters in flight at once), then single captures through the pinned host path -- every score and record identical"""
+    from stm32_speech_recognition_amd import Engine
+    eng = Engine(max_frames=119, device=0)
+    bank = synth.word_bank(25)
+    rng = np.random.default_rng(11)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(80) % 25, rng.integers(40, 120, 80), seed=8, bank=bank, S=16000))
+    store, st = eng.train_store(tp, np.arange(80), n_slots=80)
+    eng.set_templates_store(store)
+    n = 96
+    dpcm = synth.make_utterances(rng.integers(0, 25, n), rng.integers(30, 119, n), seed=9, bank=bank, S=16000,
+                                 device=torch.device("cuda", 0))
+    hpcm = dpcm.cpu().numpy().view(np.uint16)
+    eng.set_small_launch(1)
+    o = eng.alloc_outputs(n, "cuda:0", mfcc=True, vad=True)
+    eng.recognize_dev(dpcm, o)
+    torch.cuda.synchronize()
+    exp_res, exp_sc = o["results"].cpu().numpy().copy(), o["scores"].cpu().numpy().copy()
+    eng.set_small_launch(0)
+    oo = None
+    for it in range(1500):
+        b0 = int(rng.integers(0, n - 1))
+        nb = int(rng.integers(1, min(24, n - b0) + 1))
+        eng.set_pipeline(streams=3, min_chunk=int(rng.choice([1, 2, 5, 4096])), max_chunks=12)
+        if oo is None or oo["results"].shape[0] != nb:
+            oo = eng.alloc_outputs(nb, "cuda:0", mfcc=True, vad=True)
+        eng.recognize_dev(dpcm[b0:b0 + nb].contiguous(), oo)
+        torch.cuda.synchronize()
+        assert np.array_equal(oo["results"].cpu().numpy(), exp_res[b0:b0 + nb]), (it, b0, nb)
+        assert np.array_equal(oo["scores"].cpu().numpy(), exp_sc[b0:b0 + nb]), (it, b0, nb)
+    er = exp_res.view(np.uint32).reshape(n, 4)
+    for it in range(1500):
+        b = int(rng.integers(0, n))
+        r = eng.recognize(hpcm[b:b + 1], want_scores=False, want_mfcc=False, want_vad=False)["results"]
+        assert (r["best_tpl"][0], r["min_dis"][0], r["frm_num"][0], r["status"][0]) == tuple(er[b]), (it, b)
+    eng.close()
+
+
 def test_small_launch_forms_are_taken(golden):
     """one capture against an 80-slot store at the firmware's shapes: the automatic mode must pick the small-launch kernel forms
     (k_vad_wide, k_mfcc<1>, k_dtw_cells + in-kernel slot scan), which shows as at least 1.5x fewer microseconds per call than
