@@ -41,5 +41,5 @@ res = {"B": B, "K": 100,
        "reference (8 kHz, 24 Mel, 12 coef: k_mfcc + k_dtw_lds)": run(B, 100),
        "generic 8 kHz, 26 Mel, 12 coef (k_mfcc_gen + k_dtw_lds)": run(B, 100, n_mel=26),
        "generic 8 kHz, 26 Mel, 10 coef (k_mfcc_gen + k_dtw_lds on rows zero-padded to 12)": run(B, 100, n_mel=26, n_coef=10),
-       "generic 8 kHz, 26 Mel, 13 coef (k_mfcc_gen + k_dtw_gen)": run(B, 100, n_mel=26, n_coef=13)}
+       "generic 8 kHz, 26 Mel, 13 coef (k_mfcc_gen + k_dtw_lds, 16-wide rows)": run(B, 100, n_mel=26, n_coef=13)}
 print(json.dumps(res, indent=1))

@@ -145,12 +145,13 @@ __global__ void __launch_bounds__(128) k_dtw(const DtwArgs a)
     a.scores[pid] = d;
 }
 
-// ---- k_dtw_gen: the same walk for feature rows of any width (GENERIC front end, n_coef != 12) -----------------------
+// ---- k_dtw_gen: the same walk for feature rows of any width (GENERIC front end, n_coef != 12, stores that cannot be staged) ----
 // One lane per pair.  A row of n_coef <= 16 coefficients lives in eight registers as packed pairs (zero-padded: the pad
 // contributes nothing to get_dis' sum of squares, DTW.C:45-62) with its squared norm; rows are fetched coefficient by
 // coefficient (rows of an odd number of s16 are only 2-byte aligned) when the walk advances, and a distance is the norm
 // sum minus twice eight v_dot2_i32_i16 -- the arithmetic of dtw_pair above in the same u32 ring.  Stores with 12
-// coefficients never come here (k_dtw_lds / k_dtw).
+// coefficients never come here (k_dtw_lds / k_dtw); other widths only when k_dtw_lds cannot stage them (full-scale
+// coefficients, frame caps beyond the LDS).
 struct Frame16 {
     uint32_t w[8];
     uint32_t n;
@@ -257,9 +258,9 @@ struct DtwLdsArgs {
 constexpr int kDtwMaxU = 16;
 // words between utterances in the LDS image: rows are 6 words; the stride is the next value == 22 (mod 64)
 // so that equal rows of different utterances do not alias (64 banks for 8-byte reads); norms: == 11 (mod 32)
-__host__ __device__ inline uint32_t dtw_lds_row_stride(uint32_t R)
+__host__ __device__ inline uint32_t dtw_lds_row_stride(uint32_t R, uint32_t row_words = 6)
 {
-    uint32_t s = R * 6;
+    uint32_t s = R * row_words;
     return s + ((22 + 64 - (s & 63)) & 63);
 }
 __host__ __device__ inline uint32_t dtw_lds_nrm_stride(uint32_t R) { return R + ((11 + 32 - (R & 31)) & 31); }
@@ -284,6 +285,67 @@ __device__ __forceinline__ void lds_rows2(uint32_t row_off, uint32_t nrm_off, Ro
     r0 = row_from2(a0, a1, a2, np[0]);
     r1 = row_from2(b0, b1, b2, np[1]);
 }
+// ---- the row formats of k_dtw_lds: 12 coefficients (the reference, and narrower GENERIC rows zero-padded) or 16 (GENERIC
+// front end, n_coef 13..16, zero-padded).  LDS image of an utterance: kWords packed pairs per row + a separate array of norms;
+// store rows in HBM / L2: -2*coef in kWords words, the squared norm in the next word, padded to kTplBytes.
+struct Dtw12 {
+    typedef Row32 Row;  // w[0..5] coefficients, w[6] norm
+    static constexpr uint32_t kWords = 6, kLdsRowBytes = 24, kTplBytes = 32;
+    static __device__ __forceinline__ uint32_t nrm(const Row &r) { return r.w[6]; }
+    static __device__ __forceinline__ Row tpl_row(const char *p)
+    {
+        const u32x4 *q = (const u32x4 *)p;
+        return row_from(q[0], q[1]);  // (a 16 + 12 byte pair of loads, skipping the pad word, is slower: 6.44 -> 6.67 ms)
+    }
+    static __device__ __forceinline__ void rows2(uint32_t row_off, uint32_t nrm_off, Row &r0, Row &r1) { lds_rows2(row_off, nrm_off, r0, r1); }
+    static __device__ __forceinline__ int dot_acc(const Row &a, const Row &b, int c) { return dot_rows_acc(a, b, c); }
+    static __device__ __forceinline__ void copy(Row &d, const Row &s) { copy_row(d, s); }
+};
+struct Row48 {
+    uint32_t w[10];  // w[0..7] coefficients, w[8] norm, w[9] unused
+};
+struct Dtw16 {
+    typedef Row48 Row;
+    static constexpr uint32_t kWords = 8, kLdsRowBytes = 32, kTplBytes = 48;
+    static __device__ __forceinline__ uint32_t nrm(const Row &r) { return r.w[8]; }
+    static __device__ __forceinline__ Row tpl_row(const char *p)
+    {
+        const u32x4 *q = (const u32x4 *)p;
+        const u32x4 a = q[0], b = q[1], c = q[2];
+        Row r;
+        r.w[0] = a.x, r.w[1] = a.y, r.w[2] = a.z, r.w[3] = a.w, r.w[4] = b.x, r.w[5] = b.y, r.w[6] = b.z, r.w[7] = b.w;
+        r.w[8] = c.x, r.w[9] = c.y;
+        return r;
+    }
+    static __device__ __forceinline__ void rows2(uint32_t row_off, uint32_t nrm_off, Row &r0, Row &r1)
+    {
+        lds_cv_u32x2 *q = (lds_cv_u32x2 *)(uintptr_t)row_off;
+        lds_c_u32 *np = (lds_c_u32 *)(uintptr_t)nrm_off;
+        const u32x2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], b0 = q[4], b1 = q[5], b2 = q[6], b3 = q[7];
+        r0.w[0] = a0.x, r0.w[1] = a0.y, r0.w[2] = a1.x, r0.w[3] = a1.y, r0.w[4] = a2.x, r0.w[5] = a2.y, r0.w[6] = a3.x, r0.w[7] = a3.y;
+        r1.w[0] = b0.x, r1.w[1] = b0.y, r1.w[2] = b1.x, r1.w[3] = b1.y, r1.w[4] = b2.x, r1.w[5] = b2.y, r1.w[6] = b3.x, r1.w[7] = b3.y;
+        r0.w[8] = np[0], r0.w[9] = 0;
+        r1.w[8] = np[1], r1.w[9] = 0;
+    }
+    static __device__ __forceinline__ int dot_acc(const Row &a, const Row &b, int c)
+    {
+        int acc = sdot2a(a.w[0], b.w[0], c);
+#pragma unroll
+        for (int i = 1; i < 8; i++) acc = sdot2(a.w[i], b.w[i], acc);
+        return acc;
+    }
+    static __device__ __forceinline__ void copy(Row &d, const Row &s)
+    {
+#pragma unroll
+        for (int i = 0; i < 10; i += 2) {
+            u32x2 t;
+            const u32x2 v = {s.w[i], s.w[i + 1]};
+            asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(t) : "v"(v));
+            d.w[i] = t.x;
+            d.w[i + 1] = t.y;
+        }
+    }
+};
 #ifdef SR_DTW_STATS
 // development build only: wave-steps in total / on the literal path, by reason (bracket, table range, lost lane)
 __device__ unsigned long long g_dtw_stats[8];
@@ -297,8 +359,10 @@ extern "C" void sr_debug_dtw_stats(unsigned long long *out, int reset)
     }
 }
 #endif
+template <class F>  // F = Dtw12 / Dtw16: the row format
 __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 {
+    typedef typename F::Row Row;
     extern __shared__ __attribute__((aligned(16))) u32x2 smem2[];  // 8-byte typed: rows are read as ds_read_b64
     const uint32_t U = a.U, R = a.d.max_frames, K = a.d.K;
     // LDS (all of it dynamic): [tie-threshold table, tie_g bytes][rows][norms][frame counts].  The table comes FIRST, at
@@ -307,7 +371,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
     // Image of the utterances: 24-byte rows (3 x 8 bytes) + a separate array of squared norms.  Strides are padded so
     // that lanes sitting on the same row of different utterances fall on different banks.
     u32x2 *s_rows = smem2 + a.tie_g / 8;
-    const uint32_t row_stride = dtw_lds_row_stride(R), nrm_stride = dtw_lds_nrm_stride(R);  // words
+    const uint32_t row_stride = dtw_lds_row_stride(R, F::kWords), nrm_stride = dtw_lds_nrm_stride(R);  // words
     uint32_t *s_nrm = (uint32_t *)(s_rows + (size_t)U * (row_stride / 2));
     uint32_t *s_n = s_nrm + (size_t)U * nrm_stride + 8;  // frames of the workgroup's utterances, 0 = skip (+8 words: reload slack)
     const uint32_t tid = threadIdx.x, b0 = blockIdx.x * U;
@@ -328,37 +392,28 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         const uint32_t n = s_n[u];
         if (!n) continue;
         const uint32_t rows = (n + 1 < R) ? n + 1 : R;
-        const uint32_t nc = a.d.n_coef;  // 12, or fewer on the GENERIC front end: the LDS image is zero-padded to 12
+        const uint32_t nc = a.d.n_coef;  // F::kWords * 2, or fewer on the GENERIC front end: the LDS image is zero-padded
         const uint2 *src = (const uint2 *)(a.d.mfcc + (size_t)(b0 + u) * R * kCoef);
         u32x2 *dst = s_rows + (size_t)u * (row_stride / 2);
         for (uint32_t r = tid; r < rows; r += blockDim.x) {
-            uint2 q0, q1, q2;
-            if (nc == (uint32_t)kCoef) {
-                q0 = src[3 * r];
-                q1 = src[3 * r + 1];
-                q2 = src[3 * r + 2];
-            } else {  // narrower rows (2-byte aligned when nc is odd): coefficient by coefficient; zero padding adds nothing
+            uint32_t w[F::kWords];
+            if (F::kWords == 6 && nc == (uint32_t)kCoef) {
+                const uint2 q0 = src[3 * r], q1 = src[3 * r + 1], q2 = src[3 * r + 2];
+                w[0] = q0.x, w[1] = q0.y, w[2] = q1.x, w[3] = q1.y, w[4] = q2.x, w[5] = q2.y;
+            } else {  // other widths (2-byte aligned when nc is odd): coefficient by coefficient; zero padding adds nothing
                       // to get_dis' sum of squares (DTW.C:45-62)
                 const int16_t *p = a.d.mfcc + ((size_t)(b0 + u) * R + r) * nc;
-                uint32_t w[6];
 #pragma unroll
-                for (uint32_t i = 0; i < 6; i++) {
+                for (uint32_t i = 0; i < F::kWords; i++) {
                     const uint32_t lo = (2 * i < nc) ? (uint32_t)(uint16_t)p[2 * i] : 0u, hi = (2 * i + 1 < nc) ? (uint32_t)(uint16_t)p[2 * i + 1] : 0u;
                     w[i] = lo | (hi << 16);
                 }
-                q0 = make_uint2(w[0], w[1]);
-                q1 = make_uint2(w[2], w[3]);
-                q2 = make_uint2(w[4], w[5]);
             }
-            int nr = sdot2z(q0.x, q0.x);
-            nr = sdot2(q0.y, q0.y, nr);
-            nr = sdot2(q1.x, q1.x, nr);
-            nr = sdot2(q1.y, q1.y, nr);
-            nr = sdot2(q2.x, q2.x, nr);
-            nr = sdot2(q2.y, q2.y, nr);
-            dst[3 * r] = u32x2{q0.x, q0.y};
-            dst[3 * r + 1] = u32x2{q1.x, q1.y};
-            dst[3 * r + 2] = u32x2{q2.x, q2.y};
+            int nr = sdot2z(w[0], w[0]);
+#pragma unroll
+            for (uint32_t i = 1; i < F::kWords; i++) nr = sdot2(w[i], w[i], nr);
+#pragma unroll
+            for (uint32_t i = 0; i < F::kWords / 2; i++) dst[(F::kWords / 2) * r + i] = u32x2{w[2 * i], w[2 * i + 1]};
             s_nrm[u * nrm_stride + r] = (uint32_t)nr;
         }
     }
@@ -386,18 +441,15 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         // template rows through a 32-bit byte offset from the (uniform) table base: advancing it is ONE add, and the
         // loads take the base from SGPRs (a 64-bit per-lane pointer costs an add-with-carry pair per advance)
         const char *tbase = (const char *)a.tplR;
-        uint32_t t_off = ks * 32u;
-        const uint32_t t_stride = K * 32u;  // bytes per template row level (K * 32 * rows < 2^32: checked at upload)
-        auto tpl_row = [&](uint32_t off) {
-            const u32x4 *q = (const u32x4 *)(tbase + off);
-            return row_from(q[0], q[1]);  // (a 16 + 12 byte pair of loads, skipping the pad word, is slower: 6.44 -> 6.67 ms)
-        };
-        Row32 cm = tpl_row(t_off);
+        uint32_t t_off = ks * F::kTplBytes;
+        const uint32_t t_stride = K * F::kTplBytes;  // bytes per template row level (K * kTplBytes * rows < 2^32: checked at upload)
+        auto tpl_row = [&](uint32_t off) { return F::tpl_row(tbase + off); };
+        Row cm = tpl_row(t_off);
         t_off += t_stride;
-        Row32 nm = tpl_row(t_off);
-        Row32 ci, ni;
-        lds_rows2(in_off, nrm_off, ci, ni);
-        uint32_t dis = cvt_u32(sqrt_rn_int((float)(uint32_t)dot_rows_acc(cm, ci, (int)(cm.w[6] + ci.w[6]))));  // DTW.C:146
+        Row nm = tpl_row(t_off);
+        Row ci, ni;
+        F::rows2(in_off, nrm_off, ci, ni);
+        uint32_t dis = cvt_u32(sqrt_rn_int((float)(uint32_t)F::dot_acc(cm, ci, (int)(F::nrm(cm) + F::nrm(ci)))));  // DTW.C:146
         // dtw_limit (DTW.C:76-109) as an interval test per column: (x', y') is inside  <=>  lb(x') <= y' <= ub(x')
         //   ub(x') = x' < X1 ? 2x'+1 : (x'+3-c1) >> 1      (negation of DTW.C:78-91; >> floors)
         //   lb(x') = x' < X2 ? x' >> 1 : 2x'+c2-3           (negation of DTW.C:93-106)
@@ -420,10 +472,10 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             // all three candidate squared distances, unconditionally: |m|^2 + |i|^2 + (-2m).i, the norm sum seeds
             // the dot2 accumulator (template rows are stored as -2m, see upload_templates)
             // (x+1, y) first: it needs neither the template row that may still be in flight from the previous step's y advance
-            const uint32_t d_rt = (uint32_t)dot_rows_acc(cm, ni, (int)(cm.w[6] + ni.w[6]));  // (x+1, y):   get_dis(mdl, in+12)
+            const uint32_t d_rt = (uint32_t)F::dot_acc(cm, ni, (int)(F::nrm(cm) + F::nrm(ni)));  // (x+1, y):   get_dis(mdl, in+12)
             __builtin_amdgcn_sched_barrier(0);
-            const uint32_t d_up = (uint32_t)dot_rows_acc(nm, ci, (int)(nm.w[6] + ci.w[6]));  // (x, y+1):   get_dis(mdl+12, in)
-            const uint32_t d_dg = (uint32_t)dot_rows_acc(nm, ni, (int)(nm.w[6] + ni.w[6]));  // (x+1, y+1)
+            const uint32_t d_up = (uint32_t)F::dot_acc(nm, ci, (int)(F::nrm(nm) + F::nrm(ci)));  // (x, y+1):   get_dis(mdl+12, in)
+            const uint32_t d_dg = (uint32_t)F::dot_acc(nm, ni, (int)(F::nrm(nm) + F::nrm(ni)));  // (x+1, y+1)
             bool in_up = (y1 < ubA1), in_rt = (lbB < y1) & (y1 <= ubB1), in_dg = (lbB <= y1) & (y1 < ubB1);
             // DTW.C:152-184 on the SQUARED candidates.  g(d) = (u32)sqrtf((float)d) is monotone, so the step cost is
             // g(min of the admissible candidates) -- one root instead of three -- and "min == right_up" / "min == up"
@@ -521,7 +573,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             // the pace: 6 waves per SIMD, LDS-limited; this order alone is worth 6 % of the kernel's time)
             if (adv_y) {
                 y1++;
-                copy_row(cm, nm);
+                F::copy(cm, nm);
                 asm volatile("v_add_u32 %0, %1, %0" : "+v"(t_off) : "s"(t_stride));
                 nm = tpl_row(t_off);
             }
@@ -529,9 +581,9 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 // in-place updates (tied asm operands): without them the compiler builds the new values in fresh
                 // registers and copies them into the loop-carried ones at the end of the block (three v_mov per step)
                 asm volatile("v_add_u32 %0, 1, %0" : "+v"(xB));
-                asm volatile("v_add_u32 %0, 24, %0" : "+v"(in_off));
+                asm volatile("v_add_u32 %0, %1, %0" : "+v"(in_off) : "n"(F::kLdsRowBytes));
                 asm volatile("v_add_u32 %0, 4, %0" : "+v"(nrm_off));
-                lds_rows2(in_off, nrm_off, ci, ni);
+                F::rows2(in_off, nrm_off, ci, ni);
                 asm volatile("v_mov_b32 %0, %1" : "+v"(ubA1) : "v"(ubB1));
                 {
                     int ua, lb;  // (xB << 1) + constant as ONE v_lshl_add_u32 each (the compiler shares 2*xB and spends two adds)
@@ -558,9 +610,9 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 // 42 granules = 53 760 bytes -- 20 bytes more and the third one silently does not (measured: mean waves per SIMD 5.0 -> 3.3),
 // although hipOccupancyMaxActiveBlocksPerMultiprocessor still reports 3.
 constexpr size_t kLdsGranule = 1280, kCuLds = 160 * 1024;
-__host__ __device__ inline size_t dtw_lds_fixed(uint32_t U, uint32_t max_frames)
+__host__ __device__ inline size_t dtw_lds_fixed(uint32_t U, uint32_t max_frames, uint32_t row_words = 6)
 {
-    const size_t per_u = (size_t)(dtw_lds_row_stride(max_frames) + dtw_lds_nrm_stride(max_frames)) * 4;
+    const size_t per_u = (size_t)(dtw_lds_row_stride(max_frames, row_words) + dtw_lds_nrm_stride(max_frames)) * 4;
     // + 32: the reload after the last advance may read one row / two norms past the last utterance's image;
     // + the frame counts of the U utterances
     return U * per_u + 32 + ((4 * (size_t)U + 15) & ~(size_t)15);
@@ -571,7 +623,7 @@ __host__ __device__ inline size_t dtw_lds_fixed(uint32_t U, uint32_t max_frames)
 // enough resident waves to cover the LDS / L2 latency of the walk, and -- measured at K = 500 -- how many lanes share a
 // template row: the texture addresser is the limit there, and U = 6 x 167 templates runs 12 % faster than U = 2 x 500
 // (30.2 vs 34.3 ms per 65 536 utterances), while U = 10 x 100 (one workgroup per CU) loses 10 %.
-uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g, uint32_t *kc_out)
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g, uint32_t *kc_out, uint32_t row_words)
 {
     const uint32_t kMinTie = 4096;  // below 4096 every threshold is the exact square: the least useful table
     auto blocks_for = [](size_t lds) { return (uint32_t)(kCuLds / ((lds + kLdsGranule - 1) / kLdsGranule * kLdsGranule)); };
@@ -590,7 +642,7 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint
         if (chunks > 65535) continue;               // the chunks are the grid's second dimension
         kc = (K + chunks - 1) / chunks;             // equal chunks
         const uint64_t pairs = (uint64_t)U * kc;
-        const size_t lds = dtw_lds_fixed(U, max_frames);
+        const size_t lds = dtw_lds_fixed(U, max_frames, row_words);
         if (lds + kMinTie > 150 * 1024) break;
         const uint32_t waves = (uint32_t)((pairs + 63) / 64);
         uint32_t blocks = blocks_for(lds + kMinTie);
@@ -621,7 +673,7 @@ uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint
             best_kc = kc;
         }
     }
-    if (best_u && lds_bytes) *lds_bytes = dtw_lds_fixed(best_u, max_frames) + best_g;
+    if (best_u && lds_bytes) *lds_bytes = dtw_lds_fixed(best_u, max_frames, row_words) + best_g;
     if (tie_g) *tie_g = best_g;
     if (kc_out) *kc_out = best_kc;
     return best_u;
@@ -633,9 +685,9 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
     if (!n) return;
     // U (utterances per workgroup) and the LDS size were chosen once, when the template store was set
     const uint32_t U = a.tplR ? a.lds_u : 0;
-    // GENERIC front end with another feature width: up to 12 coefficients ride the staged kernel (rows zero-padded to 12 in
-    // its LDS image and in the length-sorted store); wider rows, or narrower ones whose store cannot be staged, take k_dtw_gen
-    if (a.n_coef > (uint32_t)kCoef || (a.n_coef < (uint32_t)kCoef && !U)) {
+    // GENERIC front end with another feature width: up to 12 coefficients ride the staged kernel's 12-wide form (rows zero-padded
+    // to 12 in its LDS image and in the length-sorted store), 13..16 its 16-wide form; stores that cannot be staged take k_dtw_gen
+    if (a.n_coef != (uint32_t)kCoef && !U) {
         hipLaunchKernelGGL(k_dtw_gen, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
         return;
     }
@@ -644,7 +696,8 @@ void launch_dtw(const DtwArgs &a, hipStream_t s)
         const uint32_t Kc = (a.lds_kc && a.lds_kc < a.K) ? a.lds_kc : a.K, chunks = (a.K + Kc - 1) / Kc;
         DtwLdsArgs la{a, (const u32x4 *)a.tplR, a.tpl_frames_s, a.tpl_orig, U, a.tie_delta, a.tie_g, Kc};
         const uint32_t threads = (uint32_t)(((uint64_t)U * Kc + 63) / 64 * 64);
-        hipLaunchKernelGGL(k_dtw_lds, dim3((a.B + U - 1) / U, chunks), dim3(threads), lds, s, la);
+        if (a.n_coef > (uint32_t)kCoef) hipLaunchKernelGGL(k_dtw_lds<Dtw16>, dim3((a.B + U - 1) / U, chunks), dim3(threads), lds, s, la);
+        else hipLaunchKernelGGL(k_dtw_lds<Dtw12>, dim3((a.B + U - 1) / U, chunks), dim3(threads), lds, s, la);
     } else {  // very long sequences / very many templates: generic global-memory walk
         hipLaunchKernelGGL(k_dtw, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, s, a);
     }

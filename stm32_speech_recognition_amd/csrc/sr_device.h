@@ -92,7 +92,7 @@ struct DtwArgs {
     uint32_t *scores;         // [B][K]
     sr_result *results;       // [B] (argmin kernel)
     // length-sorted, row-interleaved copy of the store for k_dtw_lds (NULL -> generic kernel)
-    const void *tplR;             // [tpl_rows][K] 32-byte rows: 12 x s16 | u32 squared norm | pad
+    const void *tplR;             // [tpl_rows][K] 32-byte rows: 12 x s16 | u32 squared norm | pad  (48-byte rows of 16 x s16 when n_coef > 12)
     const uint32_t *tpl_frames_s; // [K]
     const uint32_t *tpl_orig;     // [K]
     uint32_t lds_u;               // utterances per k_dtw_lds workgroup (0 -> generic kernel), see dtw_lds_pick_u
@@ -100,7 +100,7 @@ struct DtwArgs {
     const int8_t *tie_delta;      // DevTables::tie_delta
     uint32_t tie_g;               // entries of it the workgroup stages in LDS (a multiple of 1024, <= kTieMax)
     uint32_t lds_kc;              // templates per k_dtw_lds workgroup (dtw_lds_pick_u); the store is walked in K / lds_kc chunks
-    uint32_t n_coef;              // s16 per feature row: 12 everywhere except the GENERIC front end (-> k_dtw_gen when != 12)
+    uint32_t n_coef;              // s16 per feature row: 12 everywhere except the GENERIC front end (1..16)
     uint32_t dp_lanes;            // k_dtw_dp only: lanes per pair of the band kernel (4 / 8 / 16; 0 = default 8; 1 = k_dtw_dp_wave64)
     uint32_t *pair_count;         // k_dtw_cells only: [B] zeroed counters of finished pairs (the last one does the slot scan); may be NULL
 };
@@ -134,7 +134,8 @@ uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on th
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 // utterances per k_dtw_lds workgroup for K templates / max_frames rows (0 = use the generic kernel); tuning
 // override: development hooks dtw_u / dtw_kc / dtw_tie_g (sr_dev_hook), read when the template store is set
-uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g, uint32_t *kc);
+// (row_words: packed coefficient pairs per feature row of the staged kernel's form: 6 = up to 12 coefficients, 8 = 13..16)
+uint32_t dtw_lds_pick_u(uint32_t K, uint32_t max_frames, size_t *lds_bytes, uint32_t *tie_g, uint32_t *kc, uint32_t row_words = 6);
 void launch_argmin(const DtwArgs &a, hipStream_t s);
 void launch_dtw_dp(const DtwArgs &a, hipStream_t s);  // opt-in non-reference full-DP scorer
 // generic complex 1024-point Q15 FFT, n arrays (cr4_fft_1024_stm32 semantics)

@@ -101,7 +101,7 @@ struct sr_engine {
     uint32_t mfcc_tile = 64, mfcc_tile_small = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item (batch / small-launch form), resident workgroups
     uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension, or the generic front end's framing
     uint32_t nc = 12, n_mel = 24;                // s16 per feature row (n_coef), Mel filters
-    bool generic = false;                        // GENERIC front end (k_mfcc_gen / k_dtw_gen when nc != 12)
+    bool generic = false;                        // GENERIC front end (k_mfcc_gen; k_dtw_lds's 16-wide form when nc > 12)
     uint32_t v_durmin = 8, s_durmax = 11;        // VAD.C:72-75 in frames
     HostTables host;
     DevTables dev{};
@@ -468,28 +468,28 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
         // norm sum seeding the v_dot2 accumulator.  -2*coef must fit s16: coefficients outside [-16383, 16384]
         // (unreachable for log-Mel cepstra, reachable for arbitrary s16 records) disable the staged kernel for
         // this store and the generic k_dtw, which makes no such assumption, scores it.
-        std::vector<uint32_t> rt((size_t)rows * K * 8, 0u), fs(K);
-        if (nc > (uint32_t)kCoef) fits = false;  // wider feature rows: the generic kernel scores the store
+        // Row format: up to 12 coefficients -> 32 bytes (12 x s16, zero-padded | norm | pad); 13..16 -> 48 bytes (16 x s16 | norm | pad)
+        const uint32_t cw = nc > (uint32_t)kCoef ? 16u : (uint32_t)kCoef, rw = nc > (uint32_t)kCoef ? 12u : 8u;  // coefficients / words per row
+        std::vector<uint32_t> rt((size_t)rows * K * rw, 0u), fs(K);
         for (uint32_t ks = 0; ks < K; ks++) {
             const uint32_t k = order[ks];
             fs[ks] = v[k] ? f[k] : 0u;
-            for (uint32_t r = 0; r < rows && nc <= (uint32_t)kCoef; r++) {
-                // narrower rows (GENERIC front end, n_coef < 12) are zero-padded to 12: nothing is added to get_dis' sum
-                int16_t src[kCoef] = {0};
+            for (uint32_t r = 0; r < rows; r++) {
+                // narrower rows (GENERIC front end) are zero-padded: nothing is added to get_dis' sum
+                int16_t src[16] = {0}, neg2[16];
                 std::memcpy(src, &m[((size_t)k * rows + r) * nc], (size_t)nc * 2);
-                uint32_t *dst = &rt[((size_t)r * K + ks) * 8];
-                int16_t neg2[kCoef];
+                uint32_t *dst = &rt[((size_t)r * K + ks) * rw];
                 uint32_t nrm = 0;
-                for (int c = 0; c < kCoef; c++) {
+                for (uint32_t c = 0; c < cw; c++) {
                     nrm += (uint32_t)((int32_t)src[c] * (int32_t)src[c]);
                     if (src[c] < -16383 || src[c] > 16384) fits = false;
                     neg2[c] = (int16_t)(-2 * (int32_t)src[c]);
                 }
-                std::memcpy(dst, neg2, kCoef * 2);
-                dst[6] = nrm;
+                std::memcpy(dst, neg2, (size_t)cw * 2);
+                dst[cw / 2] = nrm;
             }
         }
-        if ((uint64_t)rows * K * 32 >= (1ull << 32)) fits = false;  // k_dtw_lds addresses the rows through a 32-bit byte offset
+        if ((uint64_t)rows * K * rw * 4 >= (1ull << 32)) fits = false;  // k_dtw_lds addresses the rows through a 32-bit byte offset
         if ((rc = n_tplR.reserve(rt.size()))) return rc;
         if ((rc = n_frames_s.reserve(K))) return rc;
         if ((rc = n_orig.reserve(K))) return rc;
@@ -524,7 +524,7 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     {
         size_t lds = 0;
         uint32_t tie_g = 0, kc = 0;
-        h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds, &tie_g, &kc) : 0;
+        h->dtw_u = h->tpl_staged_ok ? dtw_lds_pick_u(K, h->cfg.max_frames, &lds, &tie_g, &kc, nc > (uint32_t)kCoef ? 8u : 6u) : 0;
         h->dtw_lds = (uint32_t)lds;
         h->dtw_tie_g = tie_g;
         h->dtw_kc = kc;

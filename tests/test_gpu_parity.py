@@ -564,6 +564,37 @@ def test_small_launch_dtw_matches_oracle(seed):
     eng.close()
 
 
+@pytest.mark.parametrize("nc,amp", [(13, 3000), (16, 3000), (16, 16383), (15, 32767), (7, 3000)])
+def test_dtw_wide_and_narrow_feature_rows_match_oracle(nc, amp):
+    """feature rows of the GENERIC front end through the stage-level DTW call: 13..16 coefficients ride the staged kernel's
+    16-wide form (48-byte store rows, 32-byte LDS rows), up to 11 its 12-wide form with zero padding, full-scale stores
+    (coefficients beyond +-16383 do not fit the -2*coef rows) the generic walk; 1- and 2-frame records, every length gate,
+    ties (two coefficients only) in half of the records; batch kernels, one workgroup per pair, automatic"""
+    from stm32_speech_recognition_amd import Engine
+    rng = np.random.default_rng(nc * 100 + amp % 97)
+    maxf, K, B = 90, 50, 64
+    orc = ol.Oracle(max_frames=maxf, n_coef=nc)
+    eng = Engine(max_frames=maxf, device=0, n_coef=nc)
+    tf = rng.integers(1, maxf + 1, K).astype(np.uint32)
+    inf = rng.integers(1, maxf + 1, B).astype(np.uint32)
+    tf[:3], inf[:3] = [1, 2, maxf], [maxf, 1, 2]
+    tm = rng.integers(-amp, amp + 1, (K, maxf + 1, nc)).astype(np.int16)
+    im = rng.integers(-amp, amp + 1, (B, maxf, nc)).astype(np.int16)
+    tm[::2, :, 2:] = 0
+    tm[::2, :, :2] = rng.integers(0, 9, (len(tm[::2]), maxf + 1, 2))
+    im[::2, :, 2:] = 0
+    im[::2, :, :2] = rng.integers(0, 9, (len(im[::2]), maxf, 2))
+    valid = (rng.random(K) > 0.1).astype(np.uint8)
+    eng.set_templates_dense(tm, tf, valid)
+    sc, res = _dtw_all_modes(eng, im, inf)
+    pad = np.zeros((1, nc), np.int16)
+    want = np.array([[orc.dtw(np.concatenate([im[b], pad]), inf[b], tm[k], tf[k]) if valid[k] else ol.DIS_ERR
+                      for k in range(K)] for b in range(B)], dtype=np.uint32)
+    assert np.array_equal(sc, want), nc
+    assert (want != ol.DIS_ERR).sum() > 600 and np.array_equal(res["min_dis"], want.min(1))
+    eng.close()
+
+
 def test_small_launch_soak():
     """thousands of small calls in the automatic mode against one run of the batch kernels: random sub-batches of 1-24 captures
     of random lengths, cut into chunks of 1 / 2 / 5 captures on three streams (several k_dtw_cells launches and their finished-
@@ -1321,7 +1352,7 @@ def test_extension_front_end_segments_at_odd_and_first_samples():
 def test_generic_front_end_matches_oracle(ci):
     """GENERIC front end (round 4): the reference's compile-time constants (MFCC.H:7-16, VAD.H:4-8, ADC.H:7-11) as
     run-time configuration -- other sampling rates, framings, filter counts and feature widths -- through k_mfcc_gen, the
-    VAD instance of the framing and (for feature rows that are not 12 wide) k_dtw_gen.  Whole path against the
+    VAD instance of the framing and (feature rows of 13..16 coefficients) the 16-wide form of k_dtw_lds.  Whole path against the
     parametrised oracle: thresholds, every VAD segment, frame counts, MFCC s16, all scores, argmin; silent and
     over-long captures included.  No reference counterpart for the constants; every arithmetic rule is the reference's."""
     from stm32_speech_recognition_amd import Engine
