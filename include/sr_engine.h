@@ -285,10 +285,11 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
  * frames, dtw's walk), and a few of them leave the GPU idle.  The engine then spends the idle width instead:
  *   VAD   fewer than 1024 captures: a workgroup of four waves per capture (k_vad_wide) instead of one wave;
  *   MFCC  fewer than 256 work items: 4 frames per workgroup (one per wave) instead of 64 (reference front end);
- *   DTW   up to 2560 pairs per launch (1280 per workgroup that fits a CU's LDS): every pair gets its own workgroup
- *         (k_dtw_cells: all points of the in x mdl rectangle evaluated at once, then one lane follows the precomputed moves,
- *         and the last pair of an utterance does the slot scan), provided the rectangle fits a workgroup's LDS
- *         (max_frames x (longest template + 1) <= ~36 000 points and at most 1022 template frames; the firmware's 119 x 119 does);
+ *   DTW   up to 320 000 / max_frames pairs per launch (2 689 at the firmware's 119 frames, 1 000 at 320): every pair gets
+ *         its own workgroup (k_dtw_cells: all points of dtw_limit's band evaluated at once, then one lane follows the
+ *         precomputed moves, and the last pair of an utterance does the slot scan), provided the band fits a workgroup's
+ *         LDS beside the rows (frame cap and templates up to 400 frames; a pair whose band is larger than the LDS is walked
+ *         literally by its workgroup);
  *   host  sr_recognize_batch with at most 256 KB of captures: pinned staging, results written to pinned host memory.
  * Same results bit for bit (tests run the DTW / VAD / recognition cases in every mode).  One 16 000-sample capture against
  * 80 slots: 242 us -> 64 us per spch_recg call on an otherwise idle MI355X (profiles/, latency block of bench.py).

@@ -20,6 +20,7 @@ enum DevHook {
     kHookLogThrFromHost,  // "log_thr_from_host": keep the host's log step table even where it differs from the shipped one
     kHookMultiAllowDup,   // "multi_allow_dup": sr_multi_create accepts one device several times (1-GPU tests over the RCCL double)
     kHookDtwDebug,        // "dtw_debug":   print the k_dtw_lds geometry when a store is set
+    kHookCellsLiteral,    // "cells_literal": k_dtw_cells walks every pair literally (the fallback of walks that leave the band)
     kHookCount
 };
 int64_t dev_hook(DevHook h);
@@ -103,6 +104,8 @@ struct DtwArgs {
     uint32_t n_coef;              // s16 per feature row: 12 everywhere except the GENERIC front end (1..16)
     uint32_t dp_lanes;            // k_dtw_dp only: lanes per pair of the band kernel (4 / 8 / 16; 0 = default 8; 1 = k_dtw_dp_wave64)
     uint32_t *pair_count;         // k_dtw_cells only: [B] zeroed counters of finished pairs (the last one does the slot scan); may be NULL
+    uint32_t cells_points;        // k_dtw_cells only: most band points of any pair of this store (dtw_cells_max_points; 0 = kernel not usable)
+    uint32_t cells_literal;       // k_dtw_cells only: development hook "cells_literal" -- every pair takes the literal fallback walk
 };
 
 // get_mdl (DTW.C:217-296): P independent pairs

@@ -4,10 +4,13 @@
 
 namespace sr {
 
-// the pair's rows and one word per point of the in x mdl rectangle fit one workgroup's LDS (and the store has the slack rows
-// the reference's do-while reads)
+// the most points of dtw_limit's band any (utterance, template) pair of a store can have (0: not worth setting up); the
+// engine keeps it with the store and hands it over in DtwArgs::cells_points
+uint32_t dtw_cells_max_points(uint32_t max_frames, const uint32_t *frames, const uint8_t *valid, uint32_t K);
+// the pair's rows and one word per band point fit one workgroup's LDS (and the store has the slack rows the reference's
+// do-while reads)
 bool dtw_cells_fits(const DtwArgs &a);
-size_t dtw_cells_lds(uint32_t max_frames, uint32_t tpl_rows);
+size_t dtw_cells_lds(uint32_t max_frames, uint32_t tpl_rows, uint32_t max_points);
 // scores[b][k] for every pair, identical to launch_dtw's; meant for launches of a few hundred pairs
 void launch_dtw_cells(const DtwArgs &a, hipStream_t s);
 

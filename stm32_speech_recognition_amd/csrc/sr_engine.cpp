@@ -28,7 +28,7 @@ int set_error(int code, const std::string &msg) { return fail(code, msg); }  // 
 static std::atomic<int64_t> g_hooks[kHookCount];
 int64_t dev_hook(DevHook h) { return g_hooks[h].load(std::memory_order_relaxed); }
 static const char *const kHookNames[kHookCount] = {"dtw_u", "dtw_tie_g", "dtw_kc", "mfcc_grid", "perturb_log_thr",
-                                                   "log_thr_from_host", "multi_allow_dup", "dtw_debug"};
+                                                   "log_thr_from_host", "multi_allow_dup", "dtw_debug", "cells_literal"};
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -116,6 +116,7 @@ struct sr_engine {
     uint32_t K = 0, tpl_rows = 0, tpl_stride = 0;
     uint32_t dtw_u = 0, dtw_lds = 0, dtw_tie_g = 0, dtw_kc = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
     uint32_t dp_lanes = 0;         // sr_set_dp_lanes: lanes per pair of the opt-in full-DP scorer (0 = default)
+    uint32_t cells_points = 0;     // most band points of any pair of this store (k_dtw_cells' LDS; 0 = not usable)
     int small_launch = 0;          // sr_set_small_launch: 0 = k_dtw_cells for launches of a few hundred pairs, 1 = never, 2 = whenever it fits
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
@@ -535,6 +536,15 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     // Chunk count of the device-resident pipeline by store size (round-4 sweeps, profiles/experiments/RESULTS.md): with
     // 100 templates 3 streams x 6..15 chunks are equivalent (22.3 ms per 65 536 utterances); with 500 templates the DTW
     // launches dominate and fewer, longer chunks win by 1 % (3 x 6: 45.0-46.2 ms, 3 x 12: 45.2-46.7).
+    // small launches: the most band points any pair of this store can have (k_dtw_cells keeps one word per point in LDS)
+    // -- capped at what a workgroup's LDS holds beside the rows: a pair with more points than that (utterances near the frame
+    // cap against the longest templates) is walked literally by its workgroup, which costs what the batch kernel costs
+    h->cells_points = dtw_cells_max_points(h->cfg.max_frames, f.data(), v.data(), K);
+    {
+        const size_t fixed = dtw_cells_lds(h->cfg.max_frames, rows, 0), budget = 150 * 1024;
+        const size_t room = fixed < budget ? (budget - fixed) / sizeof(uint32_t) : 0;
+        if (h->cells_points > room) h->cells_points = room >= 4096 ? (uint32_t)room : 0u;
+    }
     if (!h->pipe_user_set) h->pipe_max_chunks = K >= 256 ? 6 : 12;
     h->K = K;
     h->tpl_rows = rows;
@@ -785,22 +795,19 @@ static DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_
     a.n_coef = h->nc;
     a.dp_lanes = h->dp_lanes;
     a.pair_count = nullptr;
+    a.cells_points = h->cells_points;
+    a.cells_literal = dev_hook(kHookCellsLiteral) != 0 ? 1u : 0u;
     return a;
 }
 
 // dtw for every pair of the launch: the batch kernels (k_dtw_lds / k_dtw_gen / k_dtw), or -- a few hundred pairs, i.e. a GPU
 // that would otherwise idle behind a handful of serial walks -- one workgroup per pair (k_dtw_cells).  Same scores.
-// Measured on 110-frame captures against 80 slots of up to 119 frames (66 KB of LDS per pair, two workgroups per CU;
-// profiles/experiments/RESULTS.md): 80 / 320 / 640 / 960 / 1 280 / 1 920 / 2 560 / 3 840 pairs take 25 / 30 / 45 / 54 / 67 / 92 /
-// 113 / 160 us with one workgroup per pair against 123-136 us for the batch kernel at any of these sizes.  The automatic
-// mode stops at five rounds of resident workgroups: 1 280 pairs per workgroup that fits a CU's LDS (at most 4 counted) --
-// 2 560 pairs here, where a whole call still wins (profiles/r04_small_launch_sweep.json: B = 32, 142 against 166 us).
-static uint64_t small_launch_pairs(const DtwArgs &a)
-{
-    const size_t lds = (dtw_cells_lds(a.max_frames, a.tpl_rows) + 1279) / 1280 * 1280;  // LDS granule of gfx950
-    const uint64_t per_cu = std::min<uint64_t>(4, std::max<uint64_t>(1, 160 * 1024 / lds));
-    return 1280 * per_cu;
-}
+// Measured (profiles/r04_small_launch_sweep.json, profiles/experiments/RESULTS.md): 110-frame captures against 80 slots of up
+// to 119 frames: 80 / 320 / 640 / 1 280 / 2 560 / 5 120 pairs take 25 / 33 / 44 / 65 / 115 / 212 us with one workgroup per pair
+// against 126 us for the batch kernel at any of these sizes; 256-frame captures against 100 templates of 192-320 frames (the
+// benchmark's shapes): 100 / 400 pairs 60 / 107 us against 215.  A pair costs in proportion to its band (~ frames^2), the
+// batch kernel's latency grows with the frames, so the automatic mode stops at 320 000 / max_frames pairs (2 689 / 1 000).
+static uint64_t small_launch_pairs(const DtwArgs &a) { return 320000u / (a.max_frames > 64 ? a.max_frames : 64u); }
 // returns true when the slot scan (argmin) has been done as well: k_dtw_cells with result records asked for and the utterances
 // b0 .. b0 + B of the call within the counters
 static bool launch_dtw_auto(const sr_engine *h, DtwArgs &a, uint32_t b0, hipStream_t s)

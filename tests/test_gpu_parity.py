@@ -36,8 +36,10 @@ def oracle():
 
 
 def _dtw_all_modes(eng, im, inf):
-    """sr_dtw_batch with the batch kernels (small-launch mode 1), with one workgroup per pair wherever the rectangle fits
-    (mode 2, k_dtw_cells) and in the automatic mode: scores and results must be the same bytes; returns the first"""
+    """sr_dtw_batch with the batch kernels (small-launch mode 1), with one workgroup per pair wherever the band fits
+    (mode 2, k_dtw_cells), in the automatic mode and with k_dtw_cells' literal fallback forced: scores and results must be
+    the same bytes; returns the first"""
+    from stm32_speech_recognition_amd.engine import dev_hook
     eng.set_small_launch(1)
     sc, res = eng.dtw(im, inf)
     for mode in (2, 0):
@@ -45,6 +47,16 @@ def _dtw_all_modes(eng, im, inf):
         sc2, res2 = eng.dtw(im, inf)
         assert np.array_equal(sc, sc2), mode
         assert res.tobytes() == res2.tobytes(), mode
+    # k_dtw_cells' fallback for walks that leave dtw_limit's band (a step with all three candidates outside): the literal
+    # walk on the staged rows, forced for every pair by the development hook
+    dev_hook("cells_literal", 1)
+    try:
+        eng.set_small_launch(2)
+        sc3, res3 = eng.dtw(im, inf)
+    finally:
+        dev_hook("cells_literal", 0)
+        eng.set_small_launch(0)
+    assert np.array_equal(sc, sc3) and res.tobytes() == res3.tobytes()
     return sc, res
 
 
@@ -592,6 +604,51 @@ def test_dtw_wide_and_narrow_feature_rows_match_oracle(nc, amp):
                       for k in range(K)] for b in range(B)], dtype=np.uint32)
     assert np.array_equal(sc, want), nc
     assert (want != ol.DIS_ERR).sum() > 600 and np.array_equal(res["min_dis"], want.min(1))
+    eng.close()
+
+
+def test_small_launch_at_the_benchmark_shapes():
+    """a few captures of 150..320 frames against 100 templates of 192..320 frames under a 320-frame cap (BASELINE configs[2]'s
+    shapes): dtw_limit's band of such a pair (~25 000 points) just fits a workgroup's LDS, so the automatic mode scores it
+    with k_dtw_cells; the longest captures against the longest templates do not fit and take its literal walk.  Same scores
+    and records as the batch kernels, and the call is at least 1.5x faster for one capture (measured 94 vs 286 us)."""
+    import time
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import vad_from_torch
+    dev = torch.device("cuda", 0)
+    eng = Engine(max_frames=320, device=0)
+    bank = synth.word_bank(25)
+    rng = np.random.default_rng(2026)
+    K = 100
+    tfr = rng.integers(192, 321, K)
+    tfr[:2] = [320, 192]
+    S = synth.buf_len_for(320)
+    tp = synth.make_utterances(np.arange(K) % 25, tfr, seed=77, bank=bank, S=S, device=dev)
+    tvad, tmf = eng.features_dev(tp)
+    torch.cuda.synchronize()
+    tm = np.concatenate([tmf.cpu().numpy(), np.zeros((K, 1, 12), np.int16)], 1)
+    eng.set_templates_dense(tm, vad_from_torch(tvad)["frm_num"].astype(np.uint32))
+    fr = [256, 150, 320, 300, 97, 256]
+    pcm = synth.make_utterances(rng.integers(0, 25, len(fr)), fr, seed=5, bank=bank, S=S, device=dev)
+    med = {}
+    for nb in (1, len(fr)):
+        x = pcm[:nb].contiguous()
+        got = {}
+        for mode in (1, 0, 2):
+            eng.set_small_launch(mode)
+            o = eng.alloc_outputs(nb, dev, mfcc=True, vad=True)
+            ts = []
+            for i in range(12 if nb == 1 else 2):
+                t0 = time.perf_counter()
+                eng.recognize_dev(x, o)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            got[mode] = (o["results"].cpu().numpy().copy(), o["scores"].cpu().numpy().copy())
+            med[(nb, mode)] = float(np.median(ts[2:])) if nb == 1 else 0.0
+        for mode in (0, 2):
+            assert np.array_equal(got[mode][0], got[1][0]) and np.array_equal(got[mode][1], got[1][1]), (nb, mode)
+        assert (got[1][0].view(np.uint32).reshape(nb, 4)[:, 3] == 0).all()
+    assert med[(1, 0)] * 1.5 < med[(1, 1)], med
     eng.close()
 
 
