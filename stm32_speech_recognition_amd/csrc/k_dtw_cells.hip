@@ -135,22 +135,25 @@ struct CellsBand {
 // the most band points any (utterance, template) pair of this store can have: utterances of 1..max_frames frames against the
 // lengths in the store, pairs that pass the gate of DTW.C:133-137.  0 = the small-launch kernel is not worth setting up
 // (more than 400 rows on either side: the band alone would not fit the LDS).
-uint32_t dtw_cells_max_points(uint32_t max_frames, const uint32_t *frames, const uint8_t *valid, uint32_t K)
+uint32_t dtw_cells_max_points(uint32_t max_frames, const uint32_t *frames, const uint8_t *valid, uint32_t K, std::vector<uint32_t> &by_len)
 {
     if (max_frames > 400) return 0;
-    std::vector<uint8_t> seen(402, 0);
+    if (by_len.size() != 402) by_len.assign(402, 0u);  // by_len[m]: the most points over the admissible utterance lengths (0 = not yet known)
     uint32_t best = 1;
     for (uint32_t k = 0; k < K; k++) {
         const uint32_t m = frames[k];
         if ((valid && !valid[k]) || m == 0) continue;
         if (m > 400) return 0;
-        if (seen[m]) continue;
-        seen[m] = 1;
-        for (uint32_t n = (m + 1) / 2; n <= 2 * m && n <= max_frames; n++) {
-            if (n == 0) continue;
-            const uint32_t p = CellsBand(n, m).points();
-            if (p > best) best = p;
+        if (!by_len[m]) {
+            uint32_t bm = 1;
+            for (uint32_t n = (m + 1) / 2; n <= 2 * m && n <= max_frames; n++) {
+                if (n == 0) continue;
+                const uint32_t p = CellsBand(n, m).points();
+                if (p > bm) bm = p;
+            }
+            by_len[m] = bm;
         }
+        if (by_len[m] > best) best = by_len[m];
     }
     return best;
 }

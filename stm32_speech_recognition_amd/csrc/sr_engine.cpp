@@ -117,6 +117,7 @@ struct sr_engine {
     uint32_t dtw_u = 0, dtw_lds = 0, dtw_tie_g = 0, dtw_kc = 0;  // k_dtw_lds geometry for this store (0 = generic kernel)
     uint32_t dp_lanes = 0;         // sr_set_dp_lanes: lanes per pair of the opt-in full-DP scorer (0 = default)
     uint32_t cells_points = 0;     // most band points of any pair of this store (k_dtw_cells' LDS; 0 = not usable)
+    std::vector<uint32_t> cells_by_len;  // ... per template length, computed once (dtw_cells_max_points)
     int small_launch = 0;          // sr_set_small_launch: 0 = k_dtw_cells for launches of a few hundred pairs, 1 = never, 2 = whenever it fits
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
@@ -539,7 +540,7 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
     // small launches: the most band points any pair of this store can have (k_dtw_cells keeps one word per point in LDS)
     // -- capped at what a workgroup's LDS holds beside the rows: a pair with more points than that (utterances near the frame
     // cap against the longest templates) is walked literally by its workgroup, which costs what the batch kernel costs
-    h->cells_points = dtw_cells_max_points(h->cfg.max_frames, f.data(), v.data(), K);
+    h->cells_points = dtw_cells_max_points(h->cfg.max_frames, f.data(), v.data(), K, h->cells_by_len);
     {
         const size_t fixed = dtw_cells_lds(h->cfg.max_frames, rows, 0), budget = 150 * 1024;
         const size_t room = fixed < budget ? (budget - fixed) / sizeof(uint32_t) : 0;
