@@ -284,7 +284,7 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
  * captures -- are latency-bound: every stage of the path is a serial chain per capture (VAD's state across frames, a wave's
  * frames, dtw's walk), and a few of them leave the GPU idle.  The engine then spends the idle width instead:
  *   VAD   fewer than 1024 captures: a workgroup of four waves per capture (k_vad_wide) instead of one wave;
- *   MFCC  fewer than 256 work items: 4 frames per workgroup (one per wave) instead of 64 (reference front end);
+ *   MFCC  fewer than 1024 work items of 64 frames: 16 or 4 frames per workgroup instead (reference front end);
  *   DTW   up to 320 000 / max_frames pairs per launch (2 689 at the firmware's 119 frames, 1 000 at 320): every pair gets
  *         its own workgroup (k_dtw_cells: all points of dtw_limit's band evaluated at once, then one lane follows the
  *         precomputed moves, and the last pair of an utterance does the slot scan), provided the band fits a workgroup's

@@ -10,10 +10,10 @@ namespace sr {
 // ------------------------------------------------------------------------------------------------
 constexpr int kMfccWaves = 4;       // waves per workgroup
 // consecutive frames one wave turns into MFCCs per work item: 16 in the batch form (the lane constants and tables a workgroup
-// sets up are amortised over 64 frames), 1 in the small-launch form (one capture = 110 frames is 28 workgroups instead of 2:
-// a wave's frames are a serial chain of ~1.5 us each, and with a handful of captures nothing else fills the chip;
-// 2 frames per wave: 8.1 instead of 7 us for one capture, 19 instead of 22 us for 64)
-constexpr int kFramesPerWave = 16, kFramesPerWaveSmall = 1;
+// sets up are amortised over 64 frames); 4 and 1 for launches that would leave the chip underfilled (a wave's frames are a
+// serial chain of ~1.5 us each: one capture = 110 frames is 28 workgroups of 4 frames instead of 2 of 64 -- 7 us instead of
+// 28-33 -- and 256 captures are 2 048 workgroups of 16 frames instead of 512 of 64)
+constexpr int kFramesPerWave = 16, kFramesPerWaveMid = 4, kFramesPerWaveSmall = 1;
 // per-wave LDS: exchange/scratch words + windowed frame + filterbank outputs of the wave's frames
 // rows of the filterbank outputs and of the DCT tables are kMelPad = 25 words apart: in the DCT the lanes of a wave read
 // 6 different frames x 12 different coefficients rows at the same column, and a stride of 24 folds those onto 4 banks
@@ -231,8 +231,11 @@ int mfcc_ext_occupancy(int *per_cu);
 void launch_mfcc_ext(const MfccArgs &a, uint32_t grid, hipStream_t s);
 
 uint32_t mfcc_frames_per_tile(uint32_t frame_len) { return frame_len == 320 ? mfcc_ext_frames_per_tile() : (uint32_t)(kMfccWaves * kFramesPerWave); }
-// frames per work item of the small-launch form (the extension kernel has one form)
-uint32_t mfcc_frames_per_tile_small(uint32_t frame_len) { return frame_len == 320 ? mfcc_ext_frames_per_tile() : (uint32_t)(kMfccWaves * kFramesPerWaveSmall); }
+// frames per work item of the underfilled-launch forms, 0 = mid, 1 = small (the extension kernel has one form)
+uint32_t mfcc_frames_per_tile_small(uint32_t frame_len, uint32_t which)
+{
+    return frame_len == 320 ? mfcc_ext_frames_per_tile() : (uint32_t)(kMfccWaves * (which ? kFramesPerWaveSmall : kFramesPerWaveMid));
+}
 
 // workgroups of the frame kernel that fit on the current device at once (occupancy query x CU count)
 uint32_t mfcc_resident_workgroups(uint32_t frame_len)
@@ -264,9 +267,14 @@ void launch_mfcc(const MfccArgs &a, hipStream_t s)
         launch_mfcc_ext(a, grid, s);
         return;
     }
-    if (a.small_tiles) {  // a.tiles counts tiles of mfcc_frames_per_tile_small frames
+    if (a.small_tiles == 2) {  // a.tiles counts tiles of mfcc_frames_per_tile_small(frame_len, 1) frames
         const size_t lds = (size_t)kMfccWaves * mfcc_wave_lds_words(kFramesPerWaveSmall) * sizeof(uint32_t);
         hipLaunchKernelGGL(k_mfcc<kFramesPerWaveSmall>, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
+        return;
+    }
+    if (a.small_tiles == 1) {  // ... of mfcc_frames_per_tile_small(frame_len, 0) frames
+        const size_t lds = (size_t)kMfccWaves * mfcc_wave_lds_words(kFramesPerWaveMid) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_mfcc<kFramesPerWaveMid>, dim3(grid), dim3(64 * kMfccWaves), lds, s, a);
         return;
     }
     const size_t lds = (size_t)kMfccWaves * mfcc_wave_lds_words(kFramesPerWave) * sizeof(uint32_t);

@@ -69,7 +69,7 @@ struct MfccArgs {
     const sr_vad_rec *vad;  // segment 0 + mid_val + frm_num per utterance
     int16_t *mfcc;          // [B][max_frames][12]
     uint32_t tiles;         // frame tiles per utterance
-    uint32_t small_tiles;   // 1: tiles of mfcc_frames_per_tile_small frames (k_mfcc's small-launch form)
+    uint32_t small_tiles;   // 0: 64-frame work items; 1 / 2: the 16- / 4-frame forms of k_mfcc for underfilled launches (tiles counts those)
     uint32_t n_items;       // B * tiles
     uint32_t grid_cap;      // resident workgroups of k_mfcc on this device (0 = default)
     uint32_t frame_len;     // 160 -> k_mfcc (reference front end), 320 -> k_mfcc_ext (extension)
@@ -132,7 +132,7 @@ void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, ui
 void launch_mfcc(const MfccArgs &a, hipStream_t s);
 void launch_mfcc_gen(const MfccArgs &a, hipStream_t s);  // GENERIC front end (k_mfcc_gen.hip)
 uint32_t mfcc_frames_per_tile(uint32_t frame_len);        // frames one work item of the frame kernel covers
-uint32_t mfcc_frames_per_tile_small(uint32_t frame_len);  // ... of its small-launch form (MfccArgs::small_tiles)
+uint32_t mfcc_frames_per_tile_small(uint32_t frame_len, uint32_t which);  // ... of its forms for underfilled launches (MfccArgs::small_tiles - 1)
 uint32_t mfcc_resident_workgroups(uint32_t frame_len);  // occupancy x CUs on the current device
 void launch_dtw(const DtwArgs &a, hipStream_t s);
 // utterances per k_dtw_lds workgroup for K templates / max_frames rows (0 = use the generic kernel); tuning

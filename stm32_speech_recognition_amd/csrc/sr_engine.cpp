@@ -90,7 +90,7 @@ struct DevBuf {
 using namespace sr;
 
 // launch sizes below which VAD / the frame kernel take their small-launch forms (captures; work items of 64 frames)
-static constexpr uint32_t kVadWideBelow = 1024, kMfccSmallBelow = 256;  // measured crossovers ~2 000 captures / ~256 items (RESULTS.md)
+static constexpr uint32_t kVadWideBelow = 1024, kMfccFill = 1024;  // measured crossover ~2 000 captures; work items that fill 256 CUs x 4 (RESULTS.md)
 // utterances of one call whose slot scan k_dtw_cells can do itself (one counter each); beyond that k_argmin runs as usual
 static constexpr uint32_t kPairCounters = 65536;
 
@@ -98,7 +98,7 @@ struct sr_engine {
     sr_config cfg;
     int device = 0;
     uint32_t noise_len = 0, atap_frm = 0;
-    uint32_t mfcc_tile = 64, mfcc_tile_small = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item (batch / small-launch form), resident workgroups
+    uint32_t mfcc_tile = 64, mfcc_tile_mid = 64, mfcc_tile_small = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item (batch form / the two forms for underfilled launches), resident workgroups
     uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension, or the generic front end's framing
     uint32_t nc = 12, n_mel = 24;                // s16 per feature row (n_coef), Mel filters
     bool generic = false;                        // GENERIC front end (k_mfcc_gen; k_dtw_lds's 16-wide form when nc > 12)
@@ -328,7 +328,8 @@ int sr_create(const sr_config *cfg, sr_engine **out)
         return fail(SR_ERR_BAD_CONFIG, "frame_time_ms - frame_mov_ms must not exceed 80 ms (VAD.C:72-75)");
     }
     h->mfcc_tile = h->generic ? 1u : mfcc_frames_per_tile(h->frame_len);
-    h->mfcc_tile_small = h->generic ? 1u : mfcc_frames_per_tile_small(h->frame_len);
+    h->mfcc_tile_mid = h->generic ? 1u : mfcc_frames_per_tile_small(h->frame_len, 0);
+    h->mfcc_tile_small = h->generic ? 1u : mfcc_frames_per_tile_small(h->frame_len, 1);
     // Grid of the frame kernel: FOUR times the workgroups that are resident at once, work items strided.  Exactly the
     // resident set (one persistent wave of workgroups) left ~15 % of the kernel's own time to stragglers: the workgroups
     // do not finish together, and with more, shorter ones the dispatcher back-fills the CUs that are done (measured alone
@@ -739,11 +740,19 @@ static MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pc
     a.mfcc = d_mfcc;
     a.tiles = (h->cfg.max_frames + h->mfcc_tile - 1) / h->mfcc_tile;
     a.small_tiles = 0;
-    // Fewer work items than CUs (a handful of captures: spch_recg, get_mfcc): the frame kernel's small-launch form, 4 frames per
-    // workgroup instead of 64 -- a wave's frames are a serial chain, and nothing else would fill the chip.  Same arithmetic.
-    if (h->mfcc_tile_small < h->mfcc_tile && (h->small_launch == 2 || (h->small_launch == 0 && (uint64_t)B * a.tiles < kMfccSmallBelow))) {
-        a.tiles = (h->cfg.max_frames + h->mfcc_tile_small - 1) / h->mfcc_tile_small;
-        a.small_tiles = 1;
+    // Too few 64-frame work items to fill the chip (a wave's frames are a serial chain, and nothing else would run): the frame
+    // kernel's forms with 16 or 4 frames per workgroup -- the largest whose work items reach kMfccFill, else the smallest.
+    // Same arithmetic.  (Mode 2 = always the smallest.)
+    if (h->mfcc_tile_small < h->mfcc_tile && h->small_launch != 1) {
+        const uint32_t t_mid = (h->cfg.max_frames + h->mfcc_tile_mid - 1) / h->mfcc_tile_mid;
+        const uint32_t t_small = (h->cfg.max_frames + h->mfcc_tile_small - 1) / h->mfcc_tile_small;
+        if (h->small_launch == 2 || (uint64_t)B * t_mid < kMfccFill) {
+            a.tiles = t_small;
+            a.small_tiles = 2;
+        } else if ((uint64_t)B * a.tiles < kMfccFill) {
+            a.tiles = t_mid;
+            a.small_tiles = 1;
+        }
     }
     a.grid_cap = h->mfcc_grid_cap;
     a.frame_len = h->frame_len;
