@@ -321,6 +321,12 @@ int sr_dtw_geometry(uint32_t n_templates, uint32_t max_frames, uint32_t out[5]);
  * out[3i] = (u32)(log((double)x)*100) (MFCC.C:168), out[3i+1] = (u32)sqrtf((float)x) (DTW.C:59),
  * out[3i+2] = (u32)(sqrtf((float)(s32)(x & 0x7fffffff))*10) (MFCC.C:56-58) */
 int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
+/* diagnostics: the fused Mel filterbank term of the frame kernel -- one v_mul_hi_u32 of E << 4 with ceil(tri * 2^28 / 100) --
+ * against the reference's u32 expression frq_spct[i]*tri[i]/(tri_top/10) (MFCC.C:139-161) for every weight tri in
+ * [tri_lo, tri_hi) and every energy E in [0, e_max]: mismatches[tri - tri_lo] = number of E where they differ (plus 2^40 if
+ * the weight recovered from the multiplier for the literal form is wrong).  The kernel takes the fused form while every E
+ * of a frame is <= 2 684 354 = floor(2^28 / 100). */
+int sr_mel_term_sweep(sr_engine *h, uint32_t tri_lo, uint32_t tri_hi, uint32_t e_max, uint64_t *mismatches);
 /* diagnostics: per-utterance ballots of the VAD "loud" decision (VAD.C:164), 63 frames per 64-bit word, 16 words */
 int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                        sr_vad_rec *vad, uint64_t *masks);

@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     __shared__ uint32_t s_dctM[kCoef * kMelPad];
     __shared__ int s_dctS[kCoef * kMelPad];  // 32-bit: read with the wide LDS loads, no byte extraction
     __shared__ u32x4 s_tw3[8 * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
+    __shared__ u32x4 s_tm[4 * 64];                 // filterbank multipliers of the lane's eight bins (both poly-lines)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
     uint16_t *xw = (uint16_t *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
@@ -58,12 +59,16 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     int hamm_r[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
-    // triangle weights of bins 8*lane .. 8*lane+7 of both poly-lines: 16 registers for the whole kernel
-    uint32_t tri_e[8], tri_o[8];
+    // triangle weights of bins 8*lane .. 8*lane+7 of both poly-lines as fused multipliers ceil(tri * 2^28 / 100)
+    // (sr_tables.h mel_fused_multiplier), parked in LDS as lane-contiguous 16-byte chunks like the pass-5 coefficients
+    // (chunk c of lane l at s_tm[64 c + l]: even 0-3, even 4-7, odd 0-3, odd 4-7; conflict-free ds_read_b128, and LDS
+    // instructions do not take VALU issue slots): held in 16 VGPRs for the whole kernel they pushed it past 128
+    if (w == 2 % kMfccWaves) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        tri_e[k] = a.t.tri_even32[8 * lane + k];
-        tri_o[k] = a.t.tri_odd32[8 * lane + k];
+        for (int c = 0; c < 2; c++) {
+            s_tm[64 * c + lane] = *(const u32x4 *)(a.t.tri_even_m + 8 * lane + 4 * c);
+            s_tm[64 * (c + 2) + lane] = *(const u32x4 *)(a.t.tri_odd_m + 8 * lane + 4 * c);
+        }
     }
     // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
     int f_lo = 0, f_hi = 0;
@@ -165,17 +170,42 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
                 const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
                 uint32_t se = 0, so = 0;
+                // E*tri/100 (MFCC.C:139-161): while every E of the frame is <= kMelFusedMaxE (|X|*10 <= 1638) a term is ONE
+                // v_mul_hi_u32 of E << 4 with the per-bin multiplier (the shift shared by both poly-lines): 5 instructions
+                // per bin instead of 8 (mul_lo, mul_hi, shift, add per term).  A louder frame -- decided for the whole
+                // wave, so the branch is uniform -- takes the literal u32-wrapping form with tri recovered from the multiplier.
+                const uint32_t emax = max(max(max(max(e[0], e[1]), e[2]), max(max(e[3], e[4]), e[5])), max(e[6], e[7]));
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(emax > kMelFusedMaxE) == 0, 1)) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    se += e[k] * tri_e[k] / 100u;
-                    so += e[k] * tri_o[k] / 100u;
-                    pe[k] = se;
-                    po[k] = so;
+                    for (int c = 0; c < 2; c++) {
+                        const u32x4 me = s_tm[64 * c + lane], mo = s_tm[64 * (c + 2) + lane];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t es = e[4 * c + k] << 4;
+                            se += mel_term_fused(es, me[k]);
+                            so += mel_term_fused(es, mo[k]);
+                            pe[4 * c + k] = se;
+                            po[4 * c + k] = so;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const u32x4 me = s_tm[64 * c + lane], mo = s_tm[64 * (c + 2) + lane];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            se += e[4 * c + k] * mel_tri_of_multiplier(me[k]) / 100u;
+                            so += e[4 * c + k] * mel_tri_of_multiplier(mo[k]) / 100u;
+                            pe[4 * c + k] = se;
+                            po[4 * c + k] = so;
+                        }
+                    }
                 }
                 xe = wave_scan_incl(se) - se;  // sum over the bins of the lanes below
                 xo = wave_scan_incl(so) - so;
             }
-            wave_sync();
+            // (no ordering point is needed here: a lane overwrites only the eight energies it has read itself, every other
+            // store below goes to words nobody reads before the next wave_sync)
             // in-lane prefixes and the per-lane offsets are stored separately: the 24 filter lanes add them on lookup
             // (2 adds) instead of every lane adding its offset to 16 prefixes
             *(uint4 *)(buf + 8 * lane) = make_uint4(pe[0], pe[1], pe[2], pe[3]);

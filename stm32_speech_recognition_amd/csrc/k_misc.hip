@@ -94,6 +94,30 @@ void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTa
 }
 
 // ------------------------------------------------------------------------------------------------
+// diagnostics: the fused Mel filterbank term of k_mfcc (sr_dev.h mel_term_fused / mel_tri_of_multiplier) against the
+// reference's expression frq_spct[i]*tri[i]/(tri_top/10) in u32 arithmetic (MFCC.C:139-161), for every weight tri in
+// [tri_lo, tri_hi) and every energy E in [0, e_max]: blockIdx.y = weight, threads stride over E.  Counts, per weight,
+// the E where the two differ (64-bit count; 0 everywhere is the certificate kept in profiles/).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mel_term_sweep(uint32_t tri_lo, uint32_t e_max, unsigned long long *bad)
+{
+    const uint32_t tri = tri_lo + blockIdx.y, m = mel_fused_multiplier(tri);
+    unsigned long long n = 0;
+    if (mel_tri_of_multiplier(m) != tri) n += 1ull << 40;  // the literal form would use a wrong weight
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= e_max; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t E = (uint32_t)e;
+        const uint32_t ref = E * tri / 100u;  // the reference's u32 expression (no wrap below the bound: checked against 64 bits)
+        n += (mel_term_fused(E << 4, m) != ref) || ((uint64_t)E * tri / 100u != ref);
+    }
+    if (n) atomicAdd(bad + blockIdx.y, n);
+}
+void launch_mel_term_sweep(uint32_t tri_lo, uint32_t n_tri, uint32_t e_max, unsigned long long *bad, hipStream_t s)
+{
+    if (!n_tri) return;
+    hipLaunchKernelGGL(k_mel_term_sweep, dim3(256, n_tri), dim3(256), 0, s, tri_lo, e_max, bad);
+}
+
+// ------------------------------------------------------------------------------------------------
 // scalar helpers of DTW.C exposed by the reference-compatible symbols
 // ------------------------------------------------------------------------------------------------
 __global__ void k_get_dis(const int16_t *pa, const int16_t *pb, uint32_t *out, uint32_t n)

@@ -59,6 +59,12 @@ __device__ __forceinline__ int mad24(int a, int b, int c)
     return r;
 }
 
+// One Mel filterbank term floor(E * tri / 100) (MFCC.C:139-161) for E <= kMelFusedMaxE: a single v_mul_hi_u32 of E << 4 with
+// m = mel_fused_multiplier(tri); and the weight back out of its multiplier for the literal form (sr_tables.h has the proof,
+// sr_mel_term_sweep the exhaustive check of exactly these two functions).
+__device__ __forceinline__ uint32_t mel_term_fused(uint32_t e_shl4, uint32_t m) { return __umulhi(e_shl4, m); }
+__device__ __forceinline__ uint32_t mel_tri_of_multiplier(uint32_t m) { return __umulhi(m, 1600u); }
+
 // sqrtf of an integer-valued float, correctly rounded -- bit-identical to IEEE sqrtf, hence to the reference's sqrtf calls
 // (MFCC.C:58, DTW.C:59).  Round 3: Markstein's fused correction of a reciprocal-root seed,
 //     y = v_rsq_f32(f)   s0 = f*y   h = 0.5*y   r = fma(-s0, s0, f)   s = fma(r, h, s0)

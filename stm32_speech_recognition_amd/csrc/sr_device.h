@@ -37,6 +37,8 @@ struct DevTables {
     const uint32_t *log_thr;   // [2220]
     const uint32_t *tri_even32;  // [bins] the same weights widened to 32 bits (16-byte vector loads in k_mfcc)
     const uint32_t *tri_odd32;
+    const uint32_t *tri_even_m;  // [bins] mel_fused_multiplier(tri_even[i]) (sr_tables.h): k_mfcc's filterbank terms are one v_mul_hi_u32
+    const uint32_t *tri_odd_m;
     const uint32_t *w512_a;    // [256]  EXTENSION front end only
     const uint32_t *w512_b;    // [256]
     const int8_t *tie_delta;   // [kTieMax] DTW tie thresholds: T(g) = g*(g+2) + tie_delta[g] (sr_tables.h)
@@ -155,6 +157,8 @@ void launch_unpack12(const void *packed, uint64_t row_bytes, uint16_t *out, uint
                      hipStream_t s);
 // diagnostics: log / sqrt device functions swept directly (see k_math_diag)
 void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
+// diagnostics: fused Mel filterbank term vs the reference's u32 expression, weights [tri_lo, tri_lo + n_tri), E <= e_max
+void launch_mel_term_sweep(uint32_t tri_lo, uint32_t n_tri, uint32_t e_max, unsigned long long *bad, hipStream_t s);
 // get_dis (DTW.C:45-62) for n frame pairs
 void launch_get_dis(const int16_t *a, const int16_t *b, uint32_t *out, uint32_t n, hipStream_t s);
 // dtw_limit (DTW.C:76-109) for n points with explicit statics

@@ -344,19 +344,29 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     // one blob, 16-byte aligned sub-tables
     const HostTables &t = h->host;
     std::vector<uint32_t> te32(t.tri_even.begin(), t.tri_even.end()), to32(t.tri_odd.begin(), t.tri_odd.end());
+    std::vector<uint32_t> tem(t.tri_even.size()), tom(t.tri_odd.size());
+    for (size_t i = 0; i < tem.size(); i++) {
+        if (t.tri_even[i] > kMelTriMax || t.tri_odd[i] > kMelTriMax) {
+            delete h;
+            return fail(SR_ERR_BAD_CONFIG, "internal: Mel triangle weight above the fused multiplier's range");
+        }
+        tem[i] = mel_fused_multiplier(t.tri_even[i]);
+        tom[i] = mel_fused_multiplier(t.tri_odd[i]);
+    }
     std::vector<uint32_t> hpk(t.hamm.size() / 2);
     for (size_t i = 0; i < hpk.size(); i++) hpk[i] = (uint32_t)t.hamm[2 * i] | ((uint32_t)t.hamm[2 * i + 1] << 16);
     struct Part {
         const void *src;
         size_t bytes;
         size_t off;
-    } parts[14] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
+    } parts[16] = {{t.hamm.data(), t.hamm.size() * 2, 0},       {t.tri_even.data(), t.tri_even.size() * 2, 0},
                   {t.tri_odd.data(), t.tri_odd.size() * 2, 0}, {t.tri_cen.data(), t.tri_cen.size() * 2, 0},
                   {t.dct.data(), t.dct.size(), 0},             {t.tw_a.data(), t.tw_a.size() * 4, 0},
                   {t.tw_b.data(), t.tw_b.size() * 4, 0},       {t.log_thr.data(), t.log_thr.size() * 4, 0},
                   {t.w512_a.data(), t.w512_a.size() * 4, 0},   {t.w512_b.data(), t.w512_b.size() * 4, 0},
                   {te32.data(), te32.size() * 4, 0},           {to32.data(), to32.size() * 4, 0},
-                  {t.tie_delta.data(), t.tie_delta.size(), 0}, {hpk.data(), hpk.size() * 4, 0}};
+                  {t.tie_delta.data(), t.tie_delta.size(), 0}, {hpk.data(), hpk.size() * 4, 0},
+                  {tem.data(), tem.size() * 4, 0},             {tom.data(), tom.size() * 4, 0}};
     if (t.tie_delta.size() != (size_t)kTieMax) {
         delete h;
         return fail(SR_ERR_BAD_CONFIG, "internal: DTW tie-threshold table does not fit 8 bits");
@@ -389,6 +399,8 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->dev.tri_odd32 = (const uint32_t *)(base + parts[11].off);
     h->dev.tie_delta = (const int8_t *)(base + parts[12].off);
     h->dev.hamm_pk = (const uint32_t *)(base + parts[13].off);
+    h->dev.tri_even_m = (const uint32_t *)(base + parts[14].off);
+    h->dev.tri_odd_m = (const uint32_t *)(base + parts[15].off);
     if (h->s_pcnt.reserve(kPairCounters) != SR_OK || hipMemset(h->s_pcnt.p, 0, kPairCounters * sizeof(uint32_t)) != hipSuccess) {
         sr_destroy(h);
         return fail(SR_ERR_HIP, "pair counters");
@@ -1524,6 +1536,23 @@ int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
     launch_math_diag(h->s_u32a.p, h->s_u32b.p, n, h->dev, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, h->s_u32b.p, (size_t)3 * n * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// diagnostics: k_mfcc's fused filterbank term against the reference's expression, see k_mel_term_sweep
+int sr_mel_term_sweep(sr_engine *h, uint32_t tri_lo, uint32_t tri_hi, uint32_t e_max, uint64_t *mismatches)
+{
+    if (!h || !mismatches) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (tri_hi <= tri_lo || tri_hi - tri_lo > 65535u || tri_hi - 1 > kMelTriMax || e_max >= (1u << 28))
+        return fail(SR_ERR_BAD_ARG, "sr_mel_term_sweep: weights must lie in [0, 1599], at most 65535 of them, and E below 2^28");
+    ENTER_DEVICE(h);
+    const uint32_t n = tri_hi - tri_lo;
+    int rc;
+    if ((rc = h->s_u32a.reserve((size_t)2 * n))) return rc;
+    HIP_TRY(hipMemset(h->s_u32a.p, 0, (size_t)n * 8));
+    launch_mel_term_sweep(tri_lo, n, e_max, (unsigned long long *)h->s_u32a.p, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(mismatches, h->s_u32a.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SR_OK;
 }
 

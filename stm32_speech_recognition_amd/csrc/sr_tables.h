@@ -18,6 +18,18 @@ constexpr int kTwiddles = 1020; // 3 per butterfly, passes N = 16, 64, 256, 1024
 constexpr int kLogMax = 2218;   // floor(100*ln(2^32-1))
 constexpr int kTieMax = 32768;  // entries of the DTW tie-threshold table (roots below this take the one-root step)
 
+// Mel filterbank term E * tri / (tri_top / 10) of MFCC.C:139-161 with the division folded into the multiplier (round 5):
+//     floor(E * tri / 100) == mul_hi(E << 4, M)   with   M = ceil(tri * 2^28 / 100)   for every E <= kMelFusedMaxE.
+// E*M / 2^28 = E*tri/100 + E*d/2^28 with 0 <= d < 1; the fractional part of E*tri/100 is at most 99/100, so the quotient
+// is unchanged while E*d/2^28 < 1/100, i.e. E < 2^28/100.  tri <= tri_top = 1000 keeps M below 2^32 (it needs
+// tri < 1600) and E*tri below 2^32 (no u32 wrap of the reference's product to mirror); E << 4 needs E < 2^28.
+// Certified by exhaustion on the device for every tri in 0..1000 and every E in 0..kMelFusedMaxE (sr_mel_term_sweep,
+// profiles/r05_mel_term_sweep.txt).  A frame with a larger E anywhere takes the literal form, with the weight
+// recovered as tri = mul_hi(M, 1600) = floor(M * 100 / 2^28) (exact: M*100/2^28 - tri = 100*d/2^28 < 1).
+constexpr uint32_t kMelFusedMaxE = (1u << 28) / 100u;  // 2 684 354  (|X|*10 <= 1638)
+constexpr uint32_t kMelTriMax = 1599;                  // largest weight whose multiplier fits 32 bits
+constexpr uint32_t mel_fused_multiplier(uint32_t tri) { return (uint32_t)((((uint64_t)tri << 28) + 99u) / 100u); }
+
 // The two front ends the kernels are built for: the reference's (ADC.H:7, VAD.H:5-8, MFCC.H:7-13) and the
 // 16 kHz / 512-point / 40-Mel EXTENSION of BASELINE.json configs[4] (no reference counterpart).
 struct FrontEnd {

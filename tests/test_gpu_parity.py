@@ -1828,6 +1828,65 @@ def test_development_hooks_change_geometry_not_results(golden):
         assert np.array_equal(out["scores"][:len(pcm)], golden["recg_scores"]), hooks
 
 
+def test_mel_term_fused_form_exhaustive(eng119):
+    """k_mfcc's filterbank term -- ONE v_mul_hi_u32 of E << 4 with ceil(tri * 2^28 / 100) while every energy of the frame is
+    <= floor(2^28 / 100) -- against the reference's u32 expression frq_spct[i]*tri[i]/(tri_top/10) (MFCC.C:139-161), swept on
+    the device over EVERY weight 0..1000 (tri_top; the tables hold a subset) x EVERY energy 0..2 684 354, plus the weight
+    recovered from the multiplier for the literal form.  Control: one past the certified range the fused form does fail."""
+    import ctypes as C
+    from stm32_speech_recognition_amd.engine import _vp
+    emax = (1 << 28) // 100
+    bad = np.zeros(1001, np.uint64)
+    assert eng119.L.sr_mel_term_sweep(eng119.h, C.c_uint32(0), C.c_uint32(1001), C.c_uint32(emax), _vp(bad)) == 0
+    assert not bad.any(), (np.nonzero(bad)[0][:8], bad[np.nonzero(bad)[0][:8]])
+    # control: the bound is not slack by orders of magnitude -- some weight fails somewhere below 64 x the bound
+    ctl = np.zeros(1001, np.uint64)
+    assert eng119.L.sr_mel_term_sweep(eng119.h, C.c_uint32(0), C.c_uint32(1001), C.c_uint32(min(64 * emax, (1 << 28) - 1)), _vp(ctl)) == 0
+    assert ctl.any()
+
+
+def test_filterbank_fused_and_literal_forms_match_oracle():
+    """captures at gains that put frames on both sides of the fused form's bound (and far past it, into the u32 wrap of the
+    reference's product): MFCC rows identical to the oracle's, and the oracle's own spectra confirm both forms were taken"""
+    from stm32_speech_recognition_amd import Engine
+    T, B = 64, 48
+    bank = synth.word_bank(8)
+    gains = np.repeat([0.4, 1.0, 1.6, 2.5, 4.0, 7.0], B // 6)
+    pcm = np.concatenate([synth.as_u16_numpy(synth.make_utterances(np.arange(8) % 8, [T] * 8, seed=50 + i, bank=bank, gain=float(g)))
+                          for i, g in enumerate([0.4, 1.0, 1.6, 2.5, 4.0, 7.0])])
+    assert pcm.shape[0] == B and len(gains) == B
+    orc = ol.Oracle(max_frames=T + 8)
+    eng = Engine(max_frames=T + 8, device=0)
+    hamm = orc.tables()["hamm"].astype(np.int64)
+    n_fast = n_slow = 0
+    for mode in (1, 2):  # the 64-frame batch form and the 4-frame form of the frame kernel
+        eng.set_small_launch(mode)
+        vd = eng.vad(pcm)
+        for b in range(B):
+            rc, a = orc.noise_atap(pcm[b])
+            seg = orc.vad(pcm[b], a)
+            assert (vd["seg"][b][:2] == seg[:2]).all()
+            if seg[1] < 0:
+                continue
+            n, m = orc.mfcc(pcm[b], seg[0], seg[1], a)
+            gn, gm = eng.mfcc(pcm[b:b + 1], [seg[0]], [seg[1]], [a.mid_val])
+            assert gn[0] == n and np.array_equal(gm[0, :n], m), (mode, b)
+            if mode == 1:  # which form each frame takes, from the oracle's own spectrum
+                x = pcm[b].astype(np.int64) - int(a.mid_val)
+                for f in range(0, n, 7):
+                    s0 = seg[0] + 80 * f
+                    t = x[s0:s0 + 160] - np.trunc(x[s0 - 1:s0 + 159] * 95 / 100).astype(np.int64)
+                    w = np.trunc(t * hamm / 1000).astype(np.int64).astype(np.int16)
+                    mg = orc.fft_mag(w).astype(np.uint64)
+                    if int(((mg * mg) & 0xFFFFFFFF).max()) <= (1 << 28) // 100:
+                        n_fast += 1
+                    else:
+                        n_slow += 1
+    eng.set_small_launch(0)
+    eng.close()
+    assert n_fast > 20 and n_slow > 20, (n_fast, n_slow)
+
+
 def test_log_and_sqrt_device_functions_swept_directly(eng119):
     """(u32)(log(x)*100), (u32)sqrtf(x) and (u32)(sqrtf(r)*10) as the kernels compute them, against the same C
     expressions on the host: every step position of the log table +-1, perfect squares +-1 over the whole u32
