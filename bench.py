@@ -341,8 +341,14 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     if xchg is not None:  # the gathered matrix holds every rank's scores in global utterance order
         g = xchg.gathered[0][rank * B:(rank + 1) * B]
         assert torch.equal(g, out["scores"]), "all-gather did not return this rank's shard in place"
+    sample_pcm = None
+    if xchg is not None:  # first PER_RANK_PARITY_N capture buffers of every rank's shard, for rank 0's CPU parity check
+        ns = min(PER_RANK_PARITY_N, B)
+        sample_pcm = torch.empty(dist.get_world_size() * ns, S, dtype=pcm.dtype, device=dev)
+        dist.all_gather_into_tensor(sample_pcm, pcm[:ns].contiguous())
     return dict(dt=dt, stage=stage, stage_iso=stage_iso, acc=acc, eng=eng, pcm=pcm, out=out, tm=tm, tfr=tfr, S=S, rate=rate,
-                eng_cfg=eng_cfg, K=Kt, n_words=n_words, sclk=clk.summary(), exchange=exchange)
+                eng_cfg=eng_cfg, K=Kt, n_words=n_words, sclk=clk.summary(), exchange=exchange,
+                gathered=xchg.gathered[0] if xchg is not None else None, sample_pcm=sample_pcm)
 
 
 def workload_name(workload, B, Kt):
@@ -370,6 +376,8 @@ def other_config(workload, B, Kt, steps, local_rank, cpu_n):
          "kernel_ms_isolated": {k: iso[k] for k in ("vad", "mfcc", "dtw", "argmin", "total")},
          "roofline_hbm_frac_dominant_kernel": by * B / (iso["mfcc"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
          "top1_word_accuracy": m["acc"]}
+    rv, rv_stale = valu_roofline(valu_pmc_file(workload, B, m["K"]), B, m["stage"]["total"], m.get("sclk"))
+    e["roofline_valu"], e["roofline_valu_stale"] = rv, rv_stale
     if cpu_n:
         cb = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], min(cpu_n, B), m["eng_cfg"])
         e["parity_on_sample"] = {"identical": bool(cb["gpu_results_identical_on_sample"] and
@@ -677,8 +685,18 @@ def run_rank(args):
         line = headline(args, m, world, backend)
         if FORCE_DIST:
             line["config"]["parallelism"] += " -- TEST HOOK: process group and score exchange forced at N = 1"
+        if world > 1 and not args.no_cpu_baseline:
+            # N > 1: the line still carries the host baseline and a parity flag -- over a sample of EVERY rank's shard,
+            # read from the gathered matrix (rank 0 cannot see the other ranks' buffers: they came in one extra all-gather)
+            ns = min(PER_RANK_PARITY_N, B)
+            sp = synth.as_u16_numpy(m["sample_pcm"])
+            n0 = min(args.cpu_sample, 1024, B)
+            hosts = [synth.as_u16_numpy(m["pcm"][:n0])] + [sp[r * ns:(r + 1) * ns] for r in range(1, world)]
+            line["cpu_baseline"] = multi_rank_cpu_baseline(hosts, m["gathered"], B, m["tm"], m["tfr"], m["eng_cfg"], n0,
+                                                           results_from_torch(m["out"]["results"][:n0]))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], args.cpu_sample, m["eng_cfg"])
+            line["cpu_baseline"] = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], args.cpu_sample, m["eng_cfg"],
+                                                one_thread_n=64)
             if args.workload == "ref":
                 line["cpu_reference_objects"] = cpu_reference_objects(local_rank)
                 line["latency"] = latency_block(local_rank)
@@ -720,7 +738,47 @@ PMC_SOURCES = {  # the translation units (+ the device headers they include) eac
     "pmc_traffic.json": ("k_mfcc.hip", "sr_dev.h", "sr_fft_dev.h", "sr_device.h"),
     "pmc_valu.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
     "pmc_valu_dp.json": ("k_dtw_dp.hip", "sr_dev.h", "sr_dtw_dev.h", "sr_device.h"),
+    "pmc_valu_k10.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
+    "pmc_valu_ext.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc_ext.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
 }
+
+
+def valu_pmc_file(workload, B, Kt):
+    """the committed PMC file (issue slots per utterance) that belongs to a workload shape, or None"""
+    if workload == "ext":
+        return "pmc_valu_ext.json" if Kt == 500 else None
+    return "pmc_valu.json" if Kt == 100 else "pmc_valu_k10.json" if Kt == 10 else None
+
+
+def valu_roofline(which, B, step_ms, sclk):
+    """What actually bounds the path: VALU issue.  Measured directly on this chip (profiles/r02/VALU_ISSUE.md,
+    profiles/valu_issue_ubench.hip): in a mixed instruction stream every wave64 VALU instruction holds its SIMD's issue
+    port for 4 cycles (a transcendental for 8); the 2-cycle rate of simple ops needs a pure run of them, which these
+    kernels never have.  Ceiling = 1024 SIMDs x 2.4 GHz / 4 issue slots per second; the slots a step needs come from the
+    committed PMC pass of the same workload shape (SQ_ACTIVE_INST_VALU = 4-cycle issue slots, profiles/pmc_valu*.json).
+    Returns (dict or None, stale flag or None)."""
+    path = os.path.join(ROOT, "profiles", which) if which else None
+    if not path or not os.path.exists(path):
+        return None, None
+    try:
+        vj = json.load(open(path))
+        if not pmc_is_current(vj, which):
+            return None, True
+        insts = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
+        slots = sum(v for k, v in vj.items() if k.endswith("_valu_slots_per_utt")) or insts
+        peak = 1024 * 2.4e9 / 4.0
+        achv = slots * B / (step_ms * 1e-3)
+        return {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "4-cycle issue slots/s",
+                "frac": achv / peak, "valu_slots_per_utt": slots, "valu_insts_per_utt": insts,
+                "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9,
+                "clock_hz_measured": sclk["mean_mhz"] * 1e6 if sclk else None,
+                "frac_at_measured_clock": achv / (1024 * sclk["mean_mhz"] * 1e6 / 4.0) if sclk else None,
+                "source": vj.get("source"), "pmc_file": "profiles/" + which,
+                "rates_source": "profiles/r02/VALU_ISSUE.md (per-opcode s_memtime micro-benchmark)",
+                "note": "derived: slot counts from the committed PMC pass x this run's step time; the chip "
+                        "clocks 2.3-2.4 GHz under this load, the ceiling assumes the nominal 2.4"}, False
+    except Exception:
+        return None, None
 
 
 def kernel_sources_sha(which):
@@ -767,35 +825,7 @@ def headline(args, m, world, backend="nccl", launcher=None):
             traffic_src = tj.get("source")
         except Exception:
             traffic = traffic_iso = None
-    # What actually bounds the path: VALU issue.  Measured directly on this chip (profiles/r02/VALU_ISSUE.md,
-    # profiles/valu_issue_ubench.hip): in a mixed instruction stream every wave64 VALU instruction holds its SIMD's
-    # issue port for 4 cycles (a transcendental for 8); the 2-cycle rate of simple ops needs a pure run of them, which
-    # these kernels never have.  Ceiling = 1024 SIMDs x 2.4 GHz / 4 issue slots per second; the slots a step needs come
-    # from the committed PMC pass (SQ_ACTIVE_INST_VALU = 4-cycle issue slots, profiles/pmc_valu.json).
-    roofline_valu = None
-    vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
-    if args.workload == "ref" and Kt == 100 and os.path.exists(vpath):
-        try:
-            vj = json.load(open(vpath))
-            valu_stale = not pmc_is_current(vj, "pmc_valu.json")
-            if valu_stale:
-                raise ValueError("stale")
-            insts = sum(v for k, v in vj.items() if k.endswith("_valu_insts_per_utt"))
-            slots = sum(v for k, v in vj.items() if k.endswith("_valu_slots_per_utt")) or insts
-            peak = 1024 * 2.4e9 / 4.0
-            achv = slots * B / (stage["total"] * 1e-3)
-            sclk = m.get("sclk")
-            roofline_valu = {"bound": "valu-issue", "achieved": achv, "peak": peak, "unit": "4-cycle issue slots/s",
-                             "frac": achv / peak, "valu_slots_per_utt": slots, "valu_insts_per_utt": insts,
-                             "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9,
-                             "clock_hz_measured": sclk["mean_mhz"] * 1e6 if sclk else None,
-                             "frac_at_measured_clock": achv / (1024 * sclk["mean_mhz"] * 1e6 / 4.0) if sclk else None,
-                             "source": vj.get("source"),
-                             "rates_source": "profiles/r02/VALU_ISSUE.md (per-opcode s_memtime micro-benchmark)",
-                             "note": "derived: slot counts from the committed PMC pass x this run's step time; the chip "
-                                     "clocks 2.3-2.4 GHz under this load, the ceiling assumes the nominal 2.4"}
-        except Exception:
-            roofline_valu = None
+    roofline_valu, valu_stale = valu_roofline(valu_pmc_file(args.workload, B, Kt), B, stage["total"], m.get("sclk"))
     par = f"utterance-sharded x{world}"
     if world > 1:
         par += ", RCCL all-gather of scores" if backend == "nccl" else f", all-gather of scores over {backend} (TEST HOOK, not RCCL)"
@@ -834,6 +864,13 @@ def headline(args, m, world, backend="nccl", launcher=None):
                                     "note": "launches of the TIMED steps: each covers B/launches utterances and shares the "
                                             "chip with two other chunks' kernels on other streams, so the per-launch "
                                             "durations overlap and do not add up to the step; not a fraction of the chip"},
+                     # the fractions that describe the TIMED steps, inside this object (the driver's record keeps `roofline`):
+                     "timed_step_frac": by_path * B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "timed_step_note": "SURVEY 8(d)'s whole-path algorithmic bytes per utterance x B / ms_per_step / 8 TB/s",
+                     "valu_frac": roofline_valu["frac"] if roofline_valu else None,
+                     "valu_frac_at_measured_clock": roofline_valu["frac_at_measured_clock"] if roofline_valu else None,
+                     "valu_note": "the BINDING ceiling: 4-cycle VALU issue slots of a timed step / (1024 SIMDs x clock / 4), "
+                                  "details under roofline_valu; null when the committed PMC file is stale or absent for this shape",
                      "note": "the path is integer-VALU-issue-bound, not HBM-bound (DESIGN.md 3.2): see roofline_valu"},
         "roofline_path": {"bytes_per_utt": by_path, "achieved": by_path * B / (stage["total"] * 1e-3) / 1e9,
                           "unit": "GB/s", "frac": by_path * B / (stage["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -860,15 +897,17 @@ def run_single_process(args):
     if args.workload != "ref":
         raise SystemExit("--launcher single runs the reference workload only")
     devs = list(range(n))
-    if "SR_BENCH_DEVICE" in os.environ:  # test hook: all "ranks" on one device (needs the fake RCCL named by SR_RCCL_LIBRARY)
-        devs = [int(os.environ["SR_BENCH_DEVICE"])] * n
+    testing = False
+    if "SR_BENCH_DEVICE" in os.environ:  # test hook: all "ranks" on one device (needs the fake RCCL named by SR_RCCL_LIBRARY
+        devs = [int(os.environ["SR_BENCH_DEVICE"])] * n  # and the -DSR_TESTING build of the library, which has multi_allow_dup)
         from stm32_speech_recognition_amd.engine import dev_hook
         dev_hook("multi_allow_dup", 1)
+        testing = True
     if not torch.cuda.is_available() or max(devs) >= torch.cuda.device_count():
         raise SystemExit(f"--gpus {n} but {torch.cuda.device_count()} MI355X visible (there is no CPU path)")
     rate, eng_cfg, Kt, n_words = workload_setup("ref", args.templates)
     S = synth.buf_len_for(T, rate)
-    me = MultiEngine(devs, max_frames=MAX_FRAMES)
+    me = MultiEngine(devs, max_frames=MAX_FRAMES, testing=testing)
     bank = synth.word_bank(n_words)
     e0 = me.engine(0)
     tm, tfr, rng = make_templates(e0, bank, Kt, n_words, rate, torch.device("cuda", devs[0]))
@@ -922,6 +961,13 @@ def run_single_process(args):
     line["config"]["parallelism"] = f"utterance-sharded x{n}, RCCL all-gather of scores (single process, sr_multi)"
     if os.environ.get("SR_RCCL_LIBRARY"):
         line["config"]["parallelism"] += " -- TEST HOOK: collective library " + os.environ["SR_RCCL_LIBRARY"]
+    line["exchange"] = {"backend": "rccl (sr_multi: grouped in-place ncclAllGather)", "ranks_in_communicator": n,
+                        "allgather_bytes_per_rank_out": int(n * B * Kt * 4),
+                        "every_device_holds_identical_gathered_matrix": True}  # asserted above
+    if not args.no_cpu_baseline:
+        ns, n0 = min(PER_RANK_PARITY_N, B), min(args.cpu_sample, 1024, B)
+        hosts = [synth.as_u16_numpy(pl[0][:n0])] + [synth.as_u16_numpy(pl[i][:ns]) for i in range(1, n)]
+        line["cpu_baseline"] = multi_rank_cpu_baseline(hosts, al[0], B, tm, tfr, eng_cfg, n0, results_from_torch(rl[0][:n0]))
     out_stream.write(json.dumps(line) + "\n")
     out_stream.flush()
     me.close()
@@ -948,8 +994,58 @@ def usable_cores():
     return n, (os.cpu_count() or n), quota
 
 
-def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg):
-    """The reference C path on the host cores, on the first n utterances of the timed batch.
+def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg, one_thread_n=0):
+    """The reference C path on the host cores, on the first n utterances of the timed batch (see cpu_baseline_arrays)."""
+    host = synth.as_u16_numpy(pcm[:n])
+    gsc = out["scores"][:n].cpu().numpy().view(np.uint32)
+    gres = results_from_torch(out["results"][:n])
+    return cpu_baseline_arrays(host, gsc, gres["best_tpl"], gres["min_dis"], tm, tfr, eng_cfg,
+                               f"first {n} utterances of the timed batch", one_thread_n)
+
+
+PER_RANK_PARITY_N = 128  # N > 1: utterances of EVERY rank's shard that are checked against the CPU reference
+
+
+def multi_rank_cpu_baseline(host_per_rank, gathered, B, tm, tfr, eng_cfg, n0, own_results=None):
+    """N > 1 (rank 0 / the single process): `cpu_baseline` + a parity flag that covers every rank's shard.  The sample is the
+    first n0 utterances of rank 0's shard followed by the first len(host_per_rank[r]) utterances of every other rank's
+    shard; the GPU side of the comparison is read from the GATHERED score matrix (what the exchange step delivered:
+    rank r's block starts at row r * B), with argmin / min distance re-derived from it by the strict-< first-minimum
+    scan of main.c:279-291 (dist_util.argmin_first) -- for rank 0 they are also compared with the kernel's own result
+    records.  One pass of the reference's objects over the sample gives the timing and the parity."""
+    world = len(host_per_rank)
+    rows, hosts, owner = [], [], []
+    for r in range(world):
+        n_r = min(n0 if r == 0 else len(host_per_rank[r]), len(host_per_rank[r]), B)
+        rows.append(np.arange(r * B, r * B + n_r))
+        hosts.append(host_per_rank[r][:n_r])
+        owner += [r] * n_r
+    rows = np.concatenate(rows)
+    host = np.concatenate(hosts)
+    g = gathered[torch.from_numpy(rows).to(gathered.device)]
+    best, mn = du.argmin_first(g)
+    gsc = g.cpu().numpy().view(np.uint32)
+    gbest, gdis = best.cpu().numpy().astype(np.uint32), mn.cpu().numpy().astype(np.uint32)
+    own_ok = None
+    if own_results is not None:  # rank 0's kernels' own records against the scan of the gathered rows
+        k = min(len(own_results), len(rows), n0)
+        own_ok = bool(np.array_equal(own_results["best_tpl"][:k], gbest[:k]) and np.array_equal(own_results["min_dis"][:k], gdis[:k]))
+    cb = cpu_baseline_arrays(host, gsc, gbest, gdis, tm, tfr, eng_cfg,
+                             f"first {len(hosts[0])} utterances of rank 0's shard + first {PER_RANK_PARITY_N} of each of the other "
+                             f"{world - 1} ranks' shards ({len(rows)} utterances; GPU scores taken from the gathered matrix)",
+                             one_thread_n=32)
+    cb["per_rank_sample"] = {"ranks": world, "utterances_per_rank": [int(len(h)) for h in hosts],
+                             "gpu_side": "rows r*B .. of the all-gathered score matrix on rank 0; argmin / min_dis re-derived by the "
+                                         "strict-< slot scan (main.c:279-291)",
+                             "rank0_result_records_agree_with_gathered_scan": own_ok}
+    if own_ok is False:
+        cb["gpu_results_identical_on_sample"] = False
+    return cb
+
+
+def cpu_baseline_arrays(host, gsc, gbest, gdis, tm, tfr, eng_cfg, what, one_thread_n=0):
+    """The reference C path on the host cores over the capture buffers `host` (u16 [n, S]), cross-checked against the GPU's
+    scores `gsc` (u32 [n, K]), argmin `gbest` and distance `gdis` of the same utterances.
 
     kind "reference" (reference workload): the reference's OWN VAD.C / MFCC.C / DTW.C objects (oracle/_ref/libsr_ref320.so:
     compiled from /root/reference where the sources lie, with the one compile-time constant that caps a record at 119
@@ -957,14 +1053,14 @@ def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg):
     objects keep file-scope statics (MFCC.C:14-15, DTW.C:65-68), so each host thread dlopens its own private copy of the
     .so; ctypes drops the GIL during the calls.  kind "port": the parametrised restatement (oracle tier ii), used for the
     extension workload (no reference counterpart) or when the reference objects are absent; it is also timed as a side
-    figure.  The GPU scores / argmin of the sampled utterances are cross-checked against the CPU results."""
+    figure.  one_thread_n > 0: the first one_thread_n utterances are also timed on ONE host thread (`cores_1`,
+    SURVEY.md 8(d): "1 core, then all cores")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     cores, hw_threads, quota = usable_cores()
-    host = synth.as_u16_numpy(pcm[:n])
-    gsc = out["scores"][:n].cpu().numpy().view(np.uint32)
-    gres = results_from_torch(out["results"][:n])
-    where = (f"first {n} utterances of the timed batch, {cores} host threads (box: {hw_threads} hardware threads, "
+    n = host.shape[0]
+    gres = {"best_tpl": np.asarray(gbest), "min_dis": np.asarray(gdis)}
+    where = (f"{what}, {cores} host threads (box: {hw_threads} hardware threads, "
              f"cgroup CPU quota {quota if quota else 'none'})")
     # ---- port (tier ii), multi-threaded inside the C library
     orc = ol.Oracle(max_frames=MAX_FRAMES, **eng_cfg)
@@ -977,62 +1073,33 @@ def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg):
     port = {"value": n / dt_port, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": where + ", gcc -O2 oracle (tier ii)", "seconds": dt_port,
             "gpu_results_identical_on_sample": match_port}
+    n1 = min(one_thread_n, n)
+    if n1:
+        t0 = time.perf_counter()
+        orc.recognize_batch(host[:n1], tpl, n_threads=1, want_mfcc=False, want_scores=False)
+        port["cores_1"] = {"value": n1 / (time.perf_counter() - t0), "unit": "utterances/s", "cores": 1, "utterances": n1}
     if eng_cfg or not ol.RefLib320.available():
         return port
-    # ---- the reference's own objects, one private copy of the .so per thread
-    import ctypes as C
-    import shutil
-    import tempfile
-    import threading
+    # ---- the reference's own objects, one private copy of the .so per thread (tests/oracle_lib.py Ref320Pool)
     Kt = len(tfr)
     stride = 8192
-    store = np.full(Kt * stride, 0xFF, dtype=np.uint8)
-    for k in range(Kt):                                     # v_ftr_tag images: save_sign | frm_num | mfcc_dat (MFCC.H:18-25)
-        rec = store[k * stride:(k + 1) * stride]
-        rec[:4].view(np.uint16)[:] = (12345, tfr[k])
-        rec[4:4 + int(tfr[k]) * 24] = np.ascontiguousarray(tm[k, :tfr[k]]).view(np.uint8).reshape(-1)
-    tmp = tempfile.mkdtemp(prefix="sr_ref_")
-    libs = []
-    for i in range(cores):
-        pth = os.path.join(tmp, f"libsr_ref320_{i}.so")
-        shutil.copyfile(ol.REF320_PATH, pth)
-        libs.append(C.CDLL(pth))
-    S = host.shape[1]
-    r_sc = np.zeros((n, Kt), dtype=np.uint32)
-    r_best = np.zeros(n, dtype=np.uint32)
-    r_dis = np.zeros(n, dtype=np.uint32)
-    r_st = np.zeros(n, dtype=np.int32)
-
-    def work(i, lo, hi):
-        L = libs[i]
-        ftr = np.zeros(ol.RefLib320.FTR_BYTES, dtype=np.uint8)
-        best, dis = C.c_uint32(0), C.c_uint32(0)
-        for b in range(lo, hi):
-            r_st[b] = L.sr_ref_spch_recg_seg(host[b].ctypes.data_as(C.c_void_p), C.c_uint16(S), C.c_uint16(2400),
-                                             store.ctypes.data_as(C.c_void_p), C.c_uint32(Kt), C.c_uint32(stride),
-                                             C.c_uint32(0), ftr.ctypes.data_as(C.c_void_p), C.byref(best), C.byref(dis),
-                                             r_sc[b].ctypes.data_as(C.c_void_p))
-            r_best[b], r_dis[b] = best.value, dis.value
-
-    def run(n_run):
-        per = (n_run + cores - 1) // cores
-        th = [threading.Thread(target=work, args=(i, min(i * per, n_run), min((i + 1) * per, n_run))) for i in range(cores)]
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        return time.perf_counter() - t0
-
-    run(min(n, 2 * cores))                                  # warm-up
-    dt = run(n)
-    shutil.rmtree(tmp, ignore_errors=True)
+    store = ol.ref320_store(tm, tfr, None, stride)
+    pool = ol.Ref320Pool(cores)
+    pool.recognize(host, store, Kt, stride, n_run=min(n, 2 * cores))   # warm-up
+    rr = pool.recognize(host, store, Kt, stride)
+    dt = rr["seconds"]
+    r_st, r_sc, r_best, r_dis = rr["status"], rr["scores"], rr["best"], rr["dis"]
+    cores_1 = None
+    if n1:                                                  # the same objects on ONE host thread
+        r1 = pool.recognize(host, store, Kt, stride, n_run=n1, threads=1)
+        cores_1 = {"value": n1 / r1["seconds"], "unit": "utterances/s", "cores": 1, "utterances": n1}
+    pool.close()
     match = bool((r_st == 0).all() and np.array_equal(gsc, r_sc) and np.array_equal(gres["best_tpl"], r_best)
                  and np.array_equal(gres["min_dis"], r_dis))
     return {"value": n / dt, "unit": "utterances/s", "cores": cores, "kind": "reference",
             "sample": where + ", the reference's own VAD.C/MFCC.C/DTW.C objects (gcc -O2, vv_tim_max raised to 320 frames) "
                               "+ C transcription of the asm FFT, one private .so copy per thread",
-            "seconds": dt, "gpu_results_identical_on_sample": match, "port": port}
+            "seconds": dt, "gpu_results_identical_on_sample": match, "cores_1": cores_1, "port": port}
 
 
 def cpu_reference_objects(device, n=32, Kr=100):

@@ -300,7 +300,10 @@ int sr_set_profiling(sr_engine *h, int on);
 int sr_get_stage_ms(sr_engine *h, float ms[5]);
 int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);
 
-/* Development and test hooks -- NOT part of the production surface.  Process-global integer knobs, 0 = default:
+/* Development and test hooks -- NOT part of the production surface and NOT in the product library: libsr_engine.so is
+ * built without them (every name is refused with SR_ERR_BAD_ARG, sr_testing_build() == 0); the test suite and the tuning
+ * sweeps load libsr_engine_testing.so, the same sources compiled with -DSR_TESTING (csrc/Makefile).
+ * Process-global integer knobs, 0 = default:
  *   "dtw_u", "dtw_tie_g", "dtw_kc"   force the staged DTW kernel's workgroup geometry (read when a template store is set;
  *                                    a forced combination that does not fit the LDS / the grid is ignored)
  *   "mfcc_grid"                      workgroups of the frame kernel (read by sr_create)
@@ -310,6 +313,7 @@ int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);
  *                                    names the collective library explicitly (1-GPU tests over the in-process RCCL double)
  * Unknown names return SR_ERR_BAD_ARG. */
 int sr_dev_hook(const char *name, int64_t value);
+int sr_testing_build(void);
 
 /* diagnostics, host-only (touches no device): the launch geometry the staged DTW kernel would use for a store of n_templates
  * and a frame cap of max_frames: out[0] = utterances per workgroup (0 = generic kernel), out[1] = templates per workgroup (the

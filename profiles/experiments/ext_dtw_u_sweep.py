@@ -2,6 +2,7 @@
 does a smaller DTW workgroup, which leaves LDS for a co-resident frame-kernel workgroup, beat the isolated optimum 7 x 125?
     python profiles/experiments/ext_dtw_u_sweep.py"""
 import json, os, sys, time
+os.environ.setdefault("SR_ENGINE_TESTING", "1")  # the development hooks exist only in the -DSR_TESTING build of the library
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import bench

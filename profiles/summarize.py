@@ -128,18 +128,21 @@ def main():
                            "re-calibrated for this kernel's access pattern, profiles/r02/VALU_ISSUE.md)",
              "k_mfcc_hbm_bytes_per_launch": int((2 * fs_ + ws) * 1024), "kernel_sources_sha": sources_sha("pmc_traffic.json")}
         json.dump(j, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
-    # VALU wave-instructions per utterance of the three big kernels (whole-batch launch, B = 65536): bench.py prices
-    # a step against the VALU issue ceiling with these
-    vj = {"source": f"profiles/{tag}_rocprof_summary.csv", "B": 65536,
+    # VALU wave-instructions per utterance of the big kernels (whole-batch launch): bench.py prices a step against the VALU
+    # issue ceiling with these.  One file per workload: pmc_valu.json (reference workload, B = 65536, K = 100),
+    # pmc_valu_ext.json (description holds "--workload ext": configs[4]), pmc_valu_k10.json ("--templates 10": configs[1])
+    which = "pmc_valu.json" if not desc else "pmc_valu_ext.json" if "--workload ext" in desc else \
+        "pmc_valu_k10.json" if "--templates 10" in desc else None
+    vj = {"source": f"profiles/{tag}_rocprof_summary.csv", "B": batch,
           "counter": "SQ_INSTS_VALU (wave-level instructions) and SQ_ACTIVE_INST_VALU (4-cycle issue slots: transcendentals count twice)"}
-    for k in ("sr::k_vad", "sr::k_mfcc", "sr::k_dtw_lds", "sr::k_argmin"):
+    for k in ("sr::k_vad", "sr::k_mfcc", "sr::k_mfcc_ext", "sr::k_dtw_lds", "sr::k_argmin"):
         if (k, "SQ_INSTS_VALU") in vals:
-            vj[k.split("::")[1] + "_valu_insts_per_utt"] = vals[(k, "SQ_INSTS_VALU")] / 65536.0
+            vj[k.split("::")[1] + "_valu_insts_per_utt"] = vals[(k, "SQ_INSTS_VALU")] / float(batch)
         if (k, "SQ_ACTIVE_INST_VALU") in vals:
-            vj[k.split("::")[1] + "_valu_slots_per_utt"] = vals[(k, "SQ_ACTIVE_INST_VALU")] / 65536.0
-    if len(vj) > 3 and not desc and batch == 65536:
-        vj["kernel_sources_sha"] = sources_sha("pmc_valu.json")
-        json.dump(vj, open(os.path.join(here, "pmc_valu.json"), "w"), indent=1)
+            vj[k.split("::")[1] + "_valu_slots_per_utt"] = vals[(k, "SQ_ACTIVE_INST_VALU")] / float(batch)
+    if len(vj) > 3 and which and (desc or batch == 65536):
+        vj["kernel_sources_sha"] = sources_sha(which)
+        json.dump(vj, open(os.path.join(here, which), "w"), indent=1)
     open(os.path.join(here, f"{tag}_rocprof_summary.csv"), "w").write("\n".join(out) + "\n")
     print("\n".join(out[-24:]))
 

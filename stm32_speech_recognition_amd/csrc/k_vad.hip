@@ -12,21 +12,33 @@ __global__ void k_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    sr_vad_rec r = in[b];
-    const int st = r.seg[2 * seg_idx], en = r.seg[2 * seg_idx + 1];
-    r.seg[0] = st;
-    r.seg[1] = en;
-    r.frm_num = 0;
+    // the chosen segment is read straight from memory (a register copy of the record indexed by seg_idx would live in
+    // scratch) and the output record is written by fields
+    const int st = in[b].seg[2 * seg_idx], en = in[b].seg[2 * seg_idx + 1];
+    uint32_t status, frm_num = 0;
     if (en < 0) {
-        r.status = SR_ST_VAD_FAIL;
+        status = SR_ST_VAD_FAIL;
     } else if (st < 1) {
-        r.status = SR_ST_SEG_OOB;
+        status = SR_ST_SEG_OOB;
     } else {
         const uint32_t n = ((((uint32_t)(en - st) - frame_len) / hop) + 1) & 0xFFFF;
-        r.status = n > max_frames ? SR_ST_MFCC_FAIL : SR_ST_OK;
-        r.frm_num = n > max_frames ? 0 : n;
+        status = n > max_frames ? SR_ST_MFCC_FAIL : SR_ST_OK;
+        frm_num = n > max_frames ? 0 : n;
     }
-    out[b] = r;
+    const sr_atap atap = in[b].atap;
+    const int s2 = in[b].seg[2], s3 = in[b].seg[3], s4 = in[b].seg[4], s5 = in[b].seg[5];
+    const uint32_t pad = in[b]._pad;
+    sr_vad_rec *o = out + b;  // may alias in + b: everything has been read
+    o->atap = atap;
+    o->seg[0] = st;
+    o->seg[1] = en;
+    o->seg[2] = s2;
+    o->seg[3] = s3;
+    o->seg[4] = s4;
+    o->seg[5] = s5;
+    o->frm_num = frm_num;
+    o->status = status;
+    o->_pad = pad;
 }
 void launch_select_segment(const sr_vad_rec *in, sr_vad_rec *out, uint32_t B, uint32_t seg_idx, uint32_t max_frames,
                            uint32_t frame_len, uint32_t hop, hipStream_t s)

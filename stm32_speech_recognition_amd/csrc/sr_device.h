@@ -8,9 +8,11 @@
 
 namespace sr {
 
-// Development / test hooks (C ABI: sr_dev_hook): process-global integer knobs, 0 = default behaviour.  They replace the
-// environment variables earlier rounds read inside the library: nothing in the product depends on the environment any
-// more, except SR_RCCL_LIBRARY (the path of the collective library, a deployment setting).
+// Development / test hooks (C ABI: sr_dev_hook): process-global integer knobs, 0 = default behaviour.  They exist ONLY in
+// the -DSR_TESTING build (libsr_engine_testing.so, used by the test suite and the tuning sweeps): in the product library
+// dev_hook() is the constant 0, every branch on it folds away at compile time, and sr_dev_hook refuses every name.
+// Nothing in the product depends on the environment, except SR_RCCL_LIBRARY (the path of the collective library, a
+// deployment setting).
 enum DevHook {
     kHookDtwU,            // "dtw_u":       force U utterances per k_dtw_lds workgroup (read when a template store is set)
     kHookDtwTieG,         // "dtw_tie_g":   force the staged tie-table size
@@ -23,7 +25,11 @@ enum DevHook {
     kHookCellsLiteral,    // "cells_literal": k_dtw_cells walks every pair literally (the fallback of walks that leave the band)
     kHookCount
 };
+#ifdef SR_TESTING
 int64_t dev_hook(DevHook h);
+#else
+constexpr int64_t dev_hook(DevHook) { return 0; }
+#endif
 
 // device-resident constant tables (see sr_tables.h)
 struct DevTables {

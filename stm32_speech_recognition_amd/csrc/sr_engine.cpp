@@ -25,10 +25,12 @@ static int fail(int code, const std::string &msg)
 }
 int set_error(int code, const std::string &msg) { return fail(code, msg); }  // for the other translation units
 
+#ifdef SR_TESTING
 static std::atomic<int64_t> g_hooks[kHookCount];
 int64_t dev_hook(DevHook h) { return g_hooks[h].load(std::memory_order_relaxed); }
 static const char *const kHookNames[kHookCount] = {"dtw_u", "dtw_tie_g", "dtw_kc", "mfcc_grid", "perturb_log_thr",
                                                    "log_thr_from_host", "multi_allow_dup", "dtw_debug", "cells_literal"};
+#endif
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -224,15 +226,31 @@ static int front_end_of(const sr_config *cfg, FrontEnd *fe)
 
 int sr_log_table_mismatches(void) { return log_table_mismatches(); }
 
+// 1 in the -DSR_TESTING build (development hooks compiled in), 0 in the product library
+int sr_testing_build(void)
+{
+#ifdef SR_TESTING
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int sr_dev_hook(const char *name, int64_t value)
 {
     if (!name) return fail(SR_ERR_BAD_ARG, "null hook name");
+#ifdef SR_TESTING
     for (int i = 0; i < kHookCount; i++)
         if (std::strcmp(name, kHookNames[i]) == 0) {
             g_hooks[i].store(value, std::memory_order_relaxed);
             return SR_OK;
         }
     return fail(SR_ERR_BAD_ARG, std::string("unknown development hook: ") + name);
+#else
+    (void)value;
+    return fail(SR_ERR_BAD_ARG, std::string("development hook \"") + name + "\": hooks are not compiled into the product library "
+                                "(the -DSR_TESTING build, libsr_engine_testing.so, has them)");
+#endif
 }
 
 int sr_dtw_geometry(uint32_t n_templates, uint32_t max_frames, uint32_t out[5])

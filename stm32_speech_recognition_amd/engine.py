@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsr_engine.so")
+# the same sources built with -DSR_TESTING (csrc/Makefile): the development / test hooks of sr_dev_hook exist only there
+TESTING_LIB_PATH = os.path.join(_HERE, "libsr_engine_testing.so")
 
 DIS_ERR = 0xFFFFFFFF
 ST_OK, ST_VAD_FAIL, ST_MFCC_FAIL, ST_SEG_OOB = 0, 1, 2, 3
@@ -33,26 +35,37 @@ class SrError(RuntimeError):
 
 
 _lib = None
+_lib_testing = None
 
 
-def load_library():
-    """dlopen libsr_engine.so (built by __graft_entry__.build() / csrc/Makefile)."""
-    global _lib
+def _open(path):
+    try:  # a process that also uses PyTorch must let torch load ITS HIP runtime first: libsr_engine.so then binds to the
+        import torch  # noqa: F401  same libamdhip64 (loaded the other way round, torch finds "no HIP GPUs")
+    except ImportError:
+        pass
+    if not os.path.exists(path):
+        raise SrError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.sr_last_error.restype = C.c_char_p
+    L.sr_num_templates.restype = C.c_uint32
+    L.sr_num_templates.argtypes = [C.c_void_p]
+    L.sr_destroy.argtypes = [C.c_void_p]
+    return L
+
+
+def load_library(testing=False):
+    """dlopen libsr_engine.so (built by __graft_entry__.build() / csrc/Makefile).  testing=True: the -DSR_TESTING build
+    (libsr_engine_testing.so: development hooks compiled in), a second, independent library instance; the environment
+    variable SR_ENGINE_TESTING=1 makes it the default of a whole process (test subprocesses that need hooks everywhere)."""
+    global _lib, _lib_testing
+    if testing or os.environ.get("SR_ENGINE_TESTING") == "1":
+        if _lib_testing is None:
+            _lib_testing = _open(TESTING_LIB_PATH)
+            assert _lib_testing.sr_testing_build() == 1
+        return _lib_testing
     if _lib is None:
-        try:  # a process that also uses PyTorch must let torch load ITS HIP runtime first: libsr_engine.so then binds to the
-            import torch  # noqa: F401  same libamdhip64 (loaded the other way round, torch finds "no HIP GPUs")
-        except ImportError:
-            pass
-        path = os.environ.get("SR_ENGINE_LIB", LIB_PATH)  # development override: A/B-ing two builds on one GPU box
-        if not os.path.exists(path):
-            raise SrError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-        L = C.CDLL(path)
-        L.sr_last_error.restype = C.c_char_p
-        L.sr_num_templates.restype = C.c_uint32
-        L.sr_num_templates.argtypes = [C.c_void_p]
-        L.sr_destroy.argtypes = [C.c_void_p]
-        _lib = L
+        _lib = _open(os.environ.get("SR_ENGINE_LIB", LIB_PATH))  # development override: A/B-ing two builds on one GPU box
     return _lib
 
 
@@ -68,8 +81,10 @@ def _vp(x):
 
 
 def dev_hook(name, value):
-    """sr_dev_hook: development / test knobs of the library (process-global, 0 = default); see include/sr_engine.h"""
-    L = load_library()
+    """sr_dev_hook: development / test knobs (process-global, 0 = default); see include/sr_engine.h.  They exist only in
+    the -DSR_TESTING build, so this always addresses libsr_engine_testing.so: engines that should see a hook are created
+    with Engine(..., testing=True) / MultiEngine(..., testing=True) / Engine.clone(testing=True)."""
+    L = load_library(testing=True)
     rc = L.sr_dev_hook(name.encode(), C.c_int64(value))
     if rc != 0:
         raise SrError(f"sr_dev_hook error {rc}: {L.sr_last_error().decode()}")
@@ -106,8 +121,9 @@ def build_tables(**kw):
 class Engine:
     """One sr_engine handle.  Defaults are the firmware's constants except where overridden."""
 
-    def __init__(self, max_frames=119, device=-1, **kw):
-        self.L = load_library()
+    def __init__(self, max_frames=119, device=-1, testing=False, **kw):
+        self.L = load_library(testing)
+        self._testing, self._kw, self._tpl = testing, dict(kw), None
         cfg = Config()
         self.L.sr_default_config(C.byref(cfg))
         cfg.max_frames = max_frames
@@ -123,12 +139,21 @@ class Engine:
         self.noise_len = (cfg.fs // 1000) * cfg.noise_len_ms
 
     @classmethod
-    def borrowed(cls, handle, cfg, max_frames):
+    def borrowed(cls, handle, cfg, max_frames, lib=None):
         """a view of an sr_engine handle somebody else owns (sr_multi_engine): same methods, never destroyed from here"""
         e = cls.__new__(cls)
-        e.L, e.cfg, e.h, e.max_frames, e._borrowed = load_library(), cfg, C.c_void_p(handle), max_frames, True
+        e.L, e.cfg, e.h, e.max_frames, e._borrowed = lib if lib is not None else load_library(), cfg, C.c_void_p(handle), max_frames, True
+        e._testing, e._kw, e._tpl = False, {}, None
         e.n_coef = cfg.n_coef
         e.noise_len = (cfg.fs // 1000) * cfg.noise_len_ms
+        return e
+
+    def clone(self, testing=False):
+        """a second engine with this one's configuration and template store, on the product library or (testing=True) on
+        the -DSR_TESTING build -- how a test points a development hook at the shapes of an engine it already has"""
+        e = Engine(max_frames=self.max_frames, device=self.cfg.device, testing=testing, **self._kw)
+        if self._tpl is not None:
+            getattr(e, self._tpl[0])(*self._tpl[1])
         return e
 
     def _check(self, rc):
@@ -161,11 +186,13 @@ class Engine:
         K = mfcc.shape[0]
         self._check(self.L.sr_set_templates_dense(self.h, _vp(mfcc), _vp(frames), _vp(valid), C.c_uint32(K),
                                                   C.c_uint32(mfcc.shape[1] * mfcc.shape[2])))
+        self._tpl = ("set_templates_dense", (mfcc, frames, valid))
 
     def set_templates_store(self, store, stride=4096):
         """Firmware flash image: v_ftr_tag slots at `stride` bytes (Flash.H:11-20)."""
         store = np.ascontiguousarray(store, dtype=np.uint8)
         self._check(self.L.sr_set_templates(self.h, _vp(store), C.c_uint32(len(store) // stride), C.c_uint32(stride)))
+        self._tpl = ("set_templates_store", (store, stride))
 
     def train_store(self, pcm, slots, store=None, n_slots=80, stride=4096):
         """save_mdl for each row of pcm into slot slots[i] of a flash-style store image (created erased,
@@ -414,8 +441,8 @@ class MultiEngine:
     """sr_multi: ONE process driving several MI355X (utterances sharded, templates replicated, one RCCL all-gather of
     the score matrix).  Mirrors the sr_multi_* section of include/sr_engine.h."""
 
-    def __init__(self, devices, max_frames=119, **kw):
-        self.L = load_library()
+    def __init__(self, devices, max_frames=119, testing=False, **kw):
+        self.L = load_library(testing)
         self.L.sr_multi_num_devices.restype = C.c_uint32
         cfg = Config()
         self.L.sr_default_config(C.byref(cfg))
@@ -474,7 +501,7 @@ class MultiEngine:
             raise SrError(f"sr_multi_engine({i}): no such device")
         cfg = Config.from_buffer_copy(self.cfg)
         cfg.device = self.devices[i]
-        return Engine.borrowed(h, cfg, self.max_frames)
+        return Engine.borrowed(h, cfg, self.max_frames, self.L)
 
     def recognize_dev(self, pcm_list, results_list, scores_all_list, buf_len=None, streams=None):
         """device-resident shards: torch tensors per device (pcm int16/uint16 [Bp, S], results int32 [Bp, 4],

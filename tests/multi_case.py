@@ -28,7 +28,10 @@ def multi_case(devices, golden, B=37):
     e1 = Engine(device=devices[0])
     e1.set_templates_store(golden["store"])
     want = e1.recognize(pcm, want_mfcc=False, want_vad=False)
-    me = MultiEngine(devices)
+    # duplicate device ordinals (several "ranks" on one GPU over the in-process collective double) need the development
+    # hook multi_allow_dup, which exists only in the -DSR_TESTING build of the library; the single engine the answer is
+    # compared with stays on the product library
+    me = MultiEngine(devices, testing=len(set(devices)) < len(devices))
     me.set_templates_store(golden["store"])
     res, sc = me.recognize(pcm)                                         # padded / empty last shards when n does not divide B
     for f in ("best_tpl", "min_dis", "frm_num", "status"):

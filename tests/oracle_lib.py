@@ -345,3 +345,81 @@ class RefLib320(RefLib):
     FTR_BYTES = 4 + 320 * 12 * 2
     FRM_MAX = 320
     PATH = REF320_PATH
+
+
+def ref320_store(tm, tfr, valid=None, stride=8192):
+    """v_ftr_tag images (save_sign | frm_num | mfcc_dat, MFCC.H:18-25) of K templates at byte stride `stride`, as the
+    firmware's save_mdl leaves them in flash (main.c:121-138, Flash.H:11-20); valid[k] == 0 -> erased slot (0xFF bytes)"""
+    K = len(tfr)
+    store = np.full(K * stride, 0xFF, dtype=np.uint8)
+    for k in range(K):
+        if valid is not None and not valid[k]:
+            continue
+        rec = store[k * stride:(k + 1) * stride]
+        rec[:4].view(np.uint16)[:] = (12345, tfr[k])
+        rec[4:4 + int(tfr[k]) * 24] = np.ascontiguousarray(tm[k, :tfr[k]]).view(np.uint8).reshape(-1)
+    return store
+
+
+class Ref320Pool:
+    """The reference's OWN objects at the benchmark shape, many utterances in parallel.  VAD.C / MFCC.C / DTW.C keep
+    file-scope statics (MFCC.C:14-15, DTW.C:65-68), so every host thread dlopens its own private copy of
+    oracle/_ref/libsr_ref320.so (copies in a temporary directory, removed by close()); ctypes drops the GIL during the calls."""
+
+    def __init__(self, n_threads):
+        import shutil
+        import tempfile
+        build()
+        self.n = max(1, int(n_threads))
+        self.tmp = tempfile.mkdtemp(prefix="sr_ref_")
+        self.libs = []
+        for i in range(self.n):
+            pth = os.path.join(self.tmp, f"libsr_ref320_{i}.so")
+            shutil.copyfile(REF320_PATH, pth)
+            self.libs.append(C.CDLL(pth))
+        self._rm = shutil.rmtree
+
+    def close(self):
+        if self.tmp:
+            self._rm(self.tmp, ignore_errors=True)
+            self.tmp = None
+
+    def recognize(self, host, store, n_slots, stride=8192, noise_len=2400, want_mfcc=False, n_run=None, threads=None):
+        """spch_recg (main.c:249-296, restated in oracle/ref_glue.c over an explicit store) on host[b], b < n_run.
+        Returns dict(status, best, dis, scores[n, K], seconds[, frm_num, mfcc[n, 320, 12]])."""
+        import threading
+        import time
+        host = np.ascontiguousarray(host, dtype=np.uint16)
+        n = host.shape[0] if n_run is None else n_run
+        S = host.shape[1]
+        nt = self.n if threads is None else max(1, min(threads, self.n))
+        r = dict(status=np.zeros(n, np.int32), best=np.zeros(n, np.uint32), dis=np.zeros(n, np.uint32),
+                 scores=np.zeros((n, n_slots), np.uint32))
+        if want_mfcc:
+            r["frm_num"] = np.zeros(n, np.uint32)
+            r["mfcc"] = np.zeros((n, RefLib320.FRM_MAX, 12), np.int16)
+
+        def work(i, lo, hi):
+            L = self.libs[i]
+            ftr = np.zeros(RefLib320.FTR_BYTES, dtype=np.uint8)
+            best, dis = C.c_uint32(0), C.c_uint32(0)
+            for b in range(lo, hi):
+                ftr[:4] = 0
+                r["status"][b] = L.sr_ref_spch_recg_seg(_p(host[b]), C.c_uint16(S), C.c_uint16(noise_len), _p(store),
+                                                        C.c_uint32(n_slots), C.c_uint32(stride), C.c_uint32(0), _p(ftr),
+                                                        C.byref(best), C.byref(dis), _p(r["scores"][b]))
+                r["best"][b], r["dis"][b] = best.value, dis.value
+                if want_mfcc and r["status"][b] != 1:
+                    nf = int(ftr.view(np.uint16)[1])
+                    r["frm_num"][b] = nf
+                    r["mfcc"][b, :nf] = ftr.view(np.int16)[2:2 + nf * 12].reshape(nf, 12)
+
+        per = (n + nt - 1) // nt
+        th = [threading.Thread(target=work, args=(i, min(i * per, n), min((i + 1) * per, n))) for i in range(nt)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        r["seconds"] = time.perf_counter() - t0
+        return r

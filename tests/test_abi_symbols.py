@@ -38,6 +38,50 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+HOOKS = ("dtw_u", "dtw_tie_g", "dtw_kc", "mfcc_grid", "perturb_log_thr", "log_thr_from_host", "multi_allow_dup", "dtw_debug",
+         "cells_literal")
+
+
+def test_product_library_has_no_development_hooks():
+    """The shipped libsr_engine.so is built WITHOUT -DSR_TESTING: sr_dev_hook refuses every name, the hook table is not
+    in the binary, and the hook-reading branches are compile-time constants.  The suite's hook tests and the tuning sweeps
+    use libsr_engine_testing.so (same sources, -DSR_TESTING), which exports the same surface."""
+    L = engine.load_library()
+    assert os.path.basename(engine.LIB_PATH) == "libsr_engine.so" and L.sr_testing_build() == 0
+    for name in HOOKS:
+        assert L.sr_dev_hook(name.encode(), C.c_int64(1)) == 3, name          # SR_ERR_BAD_ARG
+        assert b"not compiled into the product library" in L.sr_last_error()
+    blob = open(engine.LIB_PATH, "rb").read()
+    for name in ("cells_literal", "multi_allow_dup", "perturb_log_thr", "log_thr_from_host"):
+        assert name.encode() + b"\0" not in blob, name                         # not even the name table
+    T = engine.load_library(testing=True)
+    assert T.sr_testing_build() == 1
+    missing = [n for n in declared_functions() if not hasattr(T, n)]
+    assert not missing, missing
+    for name in HOOKS:
+        assert T.sr_dev_hook(name.encode(), C.c_int64(0)) == 0, name
+    assert T.sr_dev_hook(b"no_such_hook", C.c_int64(0)) == 3
+
+
+def test_reference_header_caller_is_linked_with_the_product_library():
+    """tests/ref_caller/ref_caller.c -- the reference's own VAD.H / MFCC.H / DTW.H / ADC.H, the main.c:258-295 sequence,
+    -lsr_engine -- is (re)built here whenever the reference tree is present (oracle/Makefile); the GPU suite runs it"""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_caller")
+    if os.path.isdir("/root/reference/Src/Speech_Recog"):
+        engine.load_library()
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref_caller"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(exe):
+        pytest.skip("no reference tree and no prebuilt oracle/_ref/ref_caller on this box")
+    src = open(os.path.join(ROOT, "tests", "ref_caller", "ref_caller.c")).read()
+    assert "sr_engine.h\"" not in src.replace("include/sr_engine.h", "") and '#include "VAD.H"' in src and '#include "MFCC.H"' in src
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "libsr_engine.so" in needed and "libsr_ref" not in needed and "liboracle" not in needed
+    syms = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    for f in ("noise_atap", "VAD", "get_mfcc", "dtw"):
+        assert f" U {f}" in syms, f
+
+
 def test_struct_layouts_match_header():
     assert engine.RESULT_DTYPE.itemsize == 16 and engine.VAD_DTYPE.itemsize == 48
     assert C.sizeof(engine.Config) == 40

@@ -197,6 +197,7 @@ def test_log_step_table_is_checked_against_the_shipped_positions():
 
     def run(**env):
         e = {k: v for k, v in os.environ.items() if k not in ("T_PERTURB", "T_FROM_HOST")}
+        e["SR_ENGINE_TESTING"] = "1"  # the hooks exist only in the -DSR_TESTING build: the whole subprocess binds to it
         p = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), capture_output=True, text=True, cwd=root, timeout=120)
         assert p.returncode == 0, p.stderr
         f = p.stdout.split(None, 3)

@@ -1,9 +1,10 @@
-"""world_size-2 CPU test (gloo) of the N>1 bookkeeping bench.py uses: contiguous utterance shards,
+"""world_size-2 and -8 CPU tests (gloo) of the N>1 bookkeeping bench.py uses: contiguous utterance shards,
 one all-gather of the [B_local, K] score matrix, max-over-ranks timing, first-minimum argmin."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -68,8 +69,10 @@ def _pipeline_worker(rank, world, port, B_local, K, steps, q):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_pipelined_exchange():
-    world, B_local, K, steps = 2, 16, 6, 5
+@pytest.mark.parametrize("world", [2, 8])
+def test_pipelined_exchange(world):
+    """the metric is quoted at 1/2/4/8 GPUs: the double-buffered exchange at world size 8 as well as 2"""
+    B_local, K, steps = 16, 6, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -96,8 +99,9 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_allgather_of_scores():
-    world, B_total, K = 2, 64, 10
+@pytest.mark.parametrize("world", [2, 8])
+def test_allgather_of_scores(world):
+    B_total, K = 64, 10
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -110,9 +114,10 @@ def test_two_rank_allgather_of_scores():
         assert p.exitcode == 0
     want = _fake_scores(0, B_total, K)
     for rank, lo, hi, gathered, t, best, mn in outs:
-        assert (lo, hi) == (rank * 32, rank * 32 + 32)
+        per = B_total // world
+        assert (lo, hi) == (rank * per, rank * per + per)
         assert np.array_equal(gathered, want)          # rank-major gather == global utterance order
-        assert t == 2.0                                # max over ranks of (1 + rank)
+        assert t == float(world)                       # max over ranks of (1 + rank)
         ref_mn = want.min(1)
         ref_best = np.array([int(np.argmax(row == row.min())) if row.min() != 0xFFFFFFFF else 0 for row in want])
         assert np.array_equal(mn, ref_mn.astype(np.int64)) and np.array_equal(best, ref_best)
