@@ -103,7 +103,12 @@ __global__ void __launch_bounds__(64 * wide::kWaves) k_vad_wide(const VadArgs a)
     __syncthreads();  // s_run is set
 
     for (uint32_t jb0 = 0; jb0 < F; jb0 += 63 * kWaves) {
-        if (s_run.done) break;  // workgroup-uniform: read after a barrier, written before it
+        // workgroup-uniform exit: every wave reads the flag the previous pass left, and only after ALL of them have read it
+        // may wave 0 rewrite s_run in round 0 of this pass (without the barrier a late wave could see this pass's "done" and
+        // leave while the others still wait at the round loop's barriers)
+        const bool was_done = s_run.done;
+        __syncthreads();
+        if (was_done) break;
         const uint32_t jb = jb0 + 63 * (uint32_t)w;
         const bool mine = jb < F;  // this wave has a round in this pass
         // ---- per-block summaries of the wave's round: no state from earlier blocks (see k_vad)
