@@ -345,7 +345,8 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     if xchg is not None:  # first PER_RANK_PARITY_N capture buffers of every rank's shard, for rank 0's CPU parity check
         ns = min(PER_RANK_PARITY_N, B)
         sample_pcm = torch.empty(dist.get_world_size() * ns, S, dtype=pcm.dtype, device=dev)
-        dist.all_gather_into_tensor(sample_pcm, pcm[:ns].contiguous())
+        # as bytes: the 16-bit sample type is not a collective dtype of every backend (gloo refuses it)
+        dist.all_gather_into_tensor(sample_pcm.view(torch.uint8), pcm[:ns].contiguous().view(torch.uint8))
     return dict(dt=dt, stage=stage, stage_iso=stage_iso, acc=acc, eng=eng, pcm=pcm, out=out, tm=tm, tfr=tfr, S=S, rate=rate,
                 eng_cfg=eng_cfg, K=Kt, n_words=n_words, sclk=clk.summary(), exchange=exchange,
                 gathered=xchg.gathered[0] if xchg is not None else None, sample_pcm=sample_pcm)

@@ -469,7 +469,7 @@ def test_bench_two_ranks_end_to_end(tmp_path):
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--batch", "4096", "--no-cpu-baseline"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.returncode == 0, p.stderr[:3000] + "\n...\n" + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     j = json.loads(lines[0])
