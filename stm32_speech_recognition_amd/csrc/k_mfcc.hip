@@ -56,9 +56,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     }
     if (w == 1 % kMfccWaves) store_tw32(s_tw5, lane, tw.s5);
     __syncthreads();
-    int hamm_r[3];
+    int hamm_m[3];  // window weights of the lane's three samples as fused multipliers (sr_tables.h hamm_fused_multiplier)
 #pragma unroll
-    for (int k = 0; k < 3; k++) hamm_r[k] = (lane + 64 * k < kFrameLen) ? (int)a.t.hamm[lane + 64 * k] : 0;
+    for (int k = 0; k < 3; k++) hamm_m[k] = (lane + 64 * k < kFrameLen) ? hamm_fused_multiplier(a.t.hamm[lane + 64 * k]) : 0;
     // triangle weights of bins 8*lane .. 8*lane+7 of both poly-lines as fused multipliers ceil(tri * 2^28 / 100)
     // (sr_tables.h mel_fused_multiplier), parked in LDS as lane-contiguous 16-byte chunks like the pass-5 coefficients
     // (chunk c of lane l at s_tm[64 c + l]: even 0-3, even 4-7, odd 0-3, odd 4-7; conflict-free ds_read_b128, and LDS
@@ -120,12 +120,8 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int i = lane + 64 * k;
-                if (i < kFrameLen) {
-                    const int cur = (int)(s_pp[k] >> 16) - mid, prv = (int)(s_pp[k] & 0xFFFFu) - mid;
-                    const int t = cur - preemph95(prv);
-                    // stored as the pass-1 output A >> 2 of the s16 sample (16-bit LDS store; the gather zero-extends)
-                    xw[i] = (uint16_t)((int)(short)(mul24(t, hamm_r[k]) / 1000) >> 2);
-                }
+                // stored as the pass-1 output A >> 2 of the s16 sample (16-bit LDS store; the gather zero-extends)
+                if (i < kFrameLen) xw[i] = (uint16_t)window_sample(s_pp[k], mid, hamm_m[k]);
             }
             if (fi + 1 < nf) {
                 const uint16_t *x = row + seg0 + (int)kHop * (int)(f0 + fi + 1);

@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
     __shared__ uint32_t s_dctM[kCoef * kMelEPad];  // same exact-division-by-100 device as k_mfcc (see there)
     __shared__ int s_dctS[kCoef * kMelEPad];
     __shared__ u32x4 s_tw4[8 * 16], s_w512[8 * 16], s_tri[8 * 16];  // per-lane constants of layout B, chunk c of lane l at [c*16 + l]
+    // window weights of the lane's 20 samples as fused multipliers (sr_tables.h hamm_fused_multiplier), layout A: chunk c of
+    // gl at [c*16 + gl] = (even, odd) sample of pair 2c, (even, odd) sample of pair 2c + 1
+    __shared__ u32x4 s_hm[5 * 16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, gl = lane & 15;
     uint32_t *xb = smem + w * kWaveWords;
@@ -69,9 +72,14 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
     }
     // ---- constants of layout A: lane = (d2, d3) --------------------------------------------------
     const int base = rev2(gl >> 2) + 4 * rev2(gl & 3);
-    uint32_t hp[10];  // Hamming weights of the lane's sample pairs (2*base + 32 t, +1)
+    if (w == 3 % kWaves && lane < 16) {  // Hamming weights of the lane's sample pairs (2*base + 32 t, +1)
 #pragma unroll
-    for (int t = 0; t < 10; t++) hp[t] = a.t.hamm_pk[base + 16 * t];
+        for (int c = 0; c < 5; c++) {
+            const uint32_t h0 = a.t.hamm_pk[base + 16 * (2 * c)], h1 = a.t.hamm_pk[base + 16 * (2 * c + 1)];
+            s_hm[c * 16 + gl] = u32x4{(uint32_t)hamm_fused_multiplier(h0 & 0xFFFFu), (uint32_t)hamm_fused_multiplier(h0 >> 16),
+                                      (uint32_t)hamm_fused_multiplier(h1 & 0xFFFFu), (uint32_t)hamm_fused_multiplier(h1 >> 16)};
+        }
+    }
     // ---- constants of layout B: lane = (d0, d1), j = gl + 16*d2 + 64*d3 ----------------------------
     uint32_t k3[4][2];  // pass 3 (q = 16, coefficient block N = 64): index j & 15 = gl
     load_tw4(a.t, 12, gl, k3);
@@ -201,12 +209,17 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
             //      the even one belongs to sub-transform 0 (slot base + 16 t), the odd one to sub-transform 1
             uint32_t ws[2][10];
 #pragma unroll
-            for (int t = 0; t < 10; t++) {
-                const int p0 = (int)(pa[t] >> 16) - mid, c0 = (int)(pb[t] & 0xFFFFu) - mid;  // x[i-1], x[i]
-                const int c1 = (int)(pb[t] >> 16) - mid, p1 = c0;                              // x[i+1], x[i]
-                const int t0 = c0 - preemph95(p0), t1 = c1 - preemph95(p1);
-                ws[0][t] = (uint32_t)(mul24(t0, (int)(hp[t] & 0xFFFFu)) / 1000) & 0xFFFFu;
-                ws[1][t] = (uint32_t)(mul24(t1, (int)(hp[t] >> 16)) / 1000) & 0xFFFFu;
+            for (int c = 0; c < 5; c++) {
+                const u32x4 hm = s_hm[c * 16 + gl];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const int t = 2 * c + h2;
+                    const int p0 = (int)(pa[t] >> 16) - mid, c0 = (int)(pb[t] & 0xFFFFu) - mid;  // x[i-1], x[i]
+                    const int c1 = (int)(pb[t] >> 16) - mid, p1 = c0;                              // x[i+1], x[i]
+                    // (s16)(temp*hamm/1000): the division folded into the weight (sr_dev.h window_quotient)
+                    ws[0][t] = (uint32_t)window_quotient(c0, neg_preemph95(p0), (int)(h2 ? hm.z : hm.x)) & 0xFFFFu;
+                    ws[1][t] = (uint32_t)window_quotient(c1, neg_preemph95(p1), (int)(h2 ? hm.w : hm.y)) & 0xFFFFu;
+                }
             }
             // ---- passes 1 and 2 of both sub-transforms in registers, then the exchange image
 #pragma unroll

@@ -48,6 +48,33 @@ __device__ __forceinline__ int sdot2a(uint32_t a, uint32_t b, int c)
 // i.e. below 0.012 in absolute terms, so truncation lands on the same integer; checked for every p of the domain with
 // the same IEEE operations in tests/test_oracle.py::test_preemphasis_float_form_is_exact.
 __device__ __forceinline__ int preemph95(int p) { return (int)((float)p * 0.95000005f); }
+// the same term negated, -(p*95/100): IEEE multiplication and the truncating conversion are symmetric in the sign
+__device__ __forceinline__ int neg_preemph95(int p) { return (int)((float)p * -0.95000005f); }
+// Pre-emphasis + Hamming weight of one sample (MFCC.C:119, 122) from the dword that holds x[i-1] (low half) and x[i] (high
+// half), as the 16-bit pattern of the pass-1 output (s16)(temp*hamm/1000) >> 2: t = (x[i] - mid) - (x[i-1] - mid)*95/100 is
+// formed already shifted by kWinShift (v_add_lshl_u32), the division by 1000 is folded into hm = hamm_fused_multiplier(hamm[i])
+// (sr_tables.h: one v_mad_i64_i32, exact on the whole domain), and the s16 wrap + ">> 2" is one v_bfe_i32.
+// the quotient trunc(t * hamm / 1000) of t = c + nq (c = x[i] - mid, nq = -((x[i-1] - mid)*95/100)), before the s16 wrap
+__device__ __forceinline__ int window_quotient(int c, int nq, int hm)
+{
+    int u;  // t << 5 in one instruction
+    asm("v_add_lshl_u32 %0, %1, %2, %3" : "=v"(u) : "v"(c), "v"(nq), "n"(kWinShift));
+    const long long P = (long long)u * (long long)hm + (long long)(unsigned long long)(uint32_t)(u >> 31);
+    return (int)(P >> 32);
+}
+__device__ __forceinline__ uint32_t window_sample(uint32_t prev_cur, int mid, int hm)
+{
+    const int nq = neg_preemph95((int)(prev_cur & 0xFFFFu) - mid);  // -((x[i-1] - mid)*95/100)
+    const int c = (int)(prev_cur >> 16) - mid;                      // x[i] - mid
+    int u;                                                          // t << 5, t = c + nq, in one instruction
+    asm("v_add_lshl_u32 %0, %1, %2, %3" : "=v"(u) : "v"(c), "v"(nq), "n"(kWinShift));
+    const long long P = (long long)u * (long long)hm + (long long)(unsigned long long)(uint32_t)(u >> 31);
+    // (s16)quotient >> 2 = bits 2..15 of the high dword, sign-extended: one v_bfe_i32 (stated as the instruction: left to the
+    // compiler the 64-bit shift became v_alignbit_b32 + v_ashrrev_i32)
+    int r;
+    asm("v_bfe_i32 %0, %1, 2, 14" : "=v"(r) : "v"((int)(P >> 32)));
+    return (uint32_t)r;
+}
 // full-rate 24-bit multiplies where the operands provably fit (quarter-rate v_mul_lo_u32 otherwise)
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ uint32_t umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }

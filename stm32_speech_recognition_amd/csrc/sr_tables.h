@@ -26,6 +26,18 @@ constexpr int kTieMax = 32768;  // entries of the DTW tie-threshold table (roots
 // Certified by exhaustion on the device for every tri in 0..1000 and every E in 0..kMelFusedMaxE (sr_mel_term_sweep,
 // profiles/r05_mel_term_sweep.txt).  A frame with a larger E anywhere takes the literal form, with the weight
 // recovered as tri = mul_hi(M, 1600) = floor(M * 100 / 2^28) (exact: M*100/2^28 - tri = 100*d/2^28 < 1).
+
+// Windowing, (s16)(temp * hamm[i] / (hamm_top / 10)) of MFCC.C:122, with the division folded into the multiplier (round 5):
+//     trunc(t * h / 1000) == (t << 5) * M + (t < 0 ? 2^32 - 1 : 0)  >> 32     with   M = ceil(h * 2^27 / 1000)
+// (64-bit signed arithmetic, arithmetic shift: ONE v_mad_i64_i32 whose 64-bit addend is the sign mask of t, zero-extended).
+// (t << 5) * M / 2^32 = t*h/1000 + t*d/2^27 with 0 <= d < 1, and |t| <= 65535 + 62258 = 127793 (a u16 sample minus a u16
+// mid value, minus 95/100 of another one) keeps |t*d/2^27| below 0.000953 < 1/1000: for t >= 0 the floor of the shift is the
+// quotient; for t < 0 adding 2^32 - 1 before the shift turns the floor into a ceiling, which is C's truncation toward zero.
+// h <= hamm_top = 10000 keeps M below 2^31.  Checked for every t of the domain x every window weight of the three front ends
+// on the host (tests/test_oracle.py::test_window_fused_multiplier_is_exact) and through the golden MFCC fixtures.
+constexpr int kWinShift = 5;
+constexpr int32_t hamm_fused_multiplier(uint32_t h) { return (int32_t)((((uint64_t)h << 27) + 999u) / 1000u); }
+
 constexpr uint32_t kMelFusedMaxE = (1u << 28) / 100u;  // 2 684 354  (|X|*10 <= 1638)
 constexpr uint32_t kMelTriMax = 1599;                  // largest weight whose multiplier fits 32 bits
 constexpr uint32_t mel_fused_multiplier(uint32_t tri) { return (uint32_t)((((uint64_t)tri << 28) + 99u) / 100u); }

@@ -178,6 +178,32 @@ def test_preemphasis_float_form_is_exact():
     assert np.array_equal(got, want)
 
 
+def test_window_fused_multiplier_is_exact():
+    """Round 5: the frame kernels fold MFCC.C:122's division by hamm_top/10 into the window weight -- trunc(t*h/1000) ==
+    ((t << 5) * ceil(h * 2^27 / 1000) + (t < 0 ? 2^32 - 1 : 0)) >> 32 in 64-bit signed arithmetic (one v_mad_i64_i32; csrc/sr_tables.h
+    hamm_fused_multiplier, sr_dev.h window_quotient) -- and take the pre-emphasis term negated (multiply by -0.95000005f).  The
+    same integer / IEEE operations here, for EVERY t the two u16 samples and the u16 mid value can produce and every window
+    weight of the two specialised front ends, against C's truncating division."""
+    from stm32_speech_recognition_amd.engine import build_tables
+    hs = set()
+    for kw in (dict(), dict(fs=16000, nfft=512, n_mel=40)):
+        hs |= set(int(v) for v in build_tables(**kw)["hamm"])
+    assert max(hs) == 10000 and len(hs) > 100
+    t = np.arange(-131071, 131072, dtype=np.int64)       # |t| <= 65535 + 62258
+    for h in sorted(hs):
+        M = (h * (1 << 27) + 999) // 1000
+        assert M < (1 << 31)
+        u = t << 5
+        P = u * M + np.where(u < 0, (1 << 32) - 1, 0).astype(np.int64)
+        v = t * h
+        want = np.where(v >= 0, v // 1000, -((-v) // 1000))
+        assert np.array_equal(P >> 32, want), h
+    p = np.arange(-65535, 65536, dtype=np.int64)
+    want = np.where(p >= 0, (p * 95) // 100, -((-p * 95) // 100))
+    got = np.trunc((p.astype(np.float32) * np.float32(-0.95000005)).astype(np.float32)).astype(np.int64)
+    assert np.array_equal(-got, want)
+
+
 def test_log_step_table_is_checked_against_the_shipped_positions():
     """MFCC.C:168 on the device is a step function whose positions sr_create finds with the HOST's libm log.  A host whose
     log differs in the last bit at one of the 2219 integer crossings would silently shift a step relative to the golden
