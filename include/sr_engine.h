@@ -290,10 +290,15 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
  *         precomputed moves, and the last pair of an utterance does the slot scan), provided the band fits a workgroup's
  *         LDS beside the rows (frame cap and templates up to 400 frames; a pair whose band is larger than the LDS is walked
  *         literally by its workgroup);
+ *         beyond that, up to two "rounds" of what the chip holds at once (65 536 pairs at the firmware's shapes): FOUR LANES
+ *         PER PAIR (k_dtw_quad: the three candidates of a step evaluated by three lanes of a quad at the same time, minimum
+ *         and move in one cross-lane reduction, both sequences staged in LDS), because the batch kernel's one-lane-per-pair
+ *         walk takes the same ~126 us for 5 000 pairs as for 160 000;
  *   host  sr_recognize_batch with at most 256 KB of captures: pinned staging, results written to pinned host memory.
  * Same results bit for bit (tests run the DTW / VAD / recognition cases in every mode).  One 16 000-sample capture against
  * 80 slots: 242 us -> 64 us per spch_recg call on an otherwise idle MI355X (profiles/, latency block of bench.py).
- * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = always (the DTW form whenever the rectangle fits),
+ * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = always (the one-workgroup-per-pair DTW form whenever
+ * the rectangle fits), 3 = the four-lanes-per-pair DTW form whenever the sequences fit (VAD / MFCC / host side as in mode 0),
  * whatever the launch size: for tests and measurements. */
 int sr_set_small_launch(sr_engine *h, int mode);
 int sr_set_profiling(sr_engine *h, int on);

@@ -1,7 +1,7 @@
 """Per-call cost of sr_recognize_batch_dev from 1 to 4096 captures at the firmware's shapes (16 000-sample capture, 110-frame
-word, 80 slots of 70-119 frames), with the small-launch kernel forms switched off (sr_set_small_launch 1), automatic (0) and
-forced (2): where each form stops paying.  Medians of the host wall clock over 30 calls + hipEvent-bracketed kernels.
-    python profiles/experiments/small_launch_sweep.py > profiles/r04_small_launch_sweep.json
+word, 80 slots of 70-119 frames), with the small-launch kernel forms switched off (sr_set_small_launch 1), automatic (0),
+one workgroup per pair forced (2) and four lanes per pair forced (3, round 5): where each form stops paying.  Medians of the host wall clock over 30 calls + hipEvent-bracketed kernels.
+    python profiles/experiments/small_launch_sweep.py > profiles/r05_small_launch_sweep.json
 """
 import json
 import os
@@ -31,7 +31,7 @@ def main():
     for Bs in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
         o = eng.alloc_outputs(Bs, "cuda:0", mfcc=False, vad=False)
         row = {"B": Bs, "pairs": Bs * Kl}
-        for mode, name in ((1, "batch_kernels"), (0, "automatic"), (2, "forced")):
+        for mode, name in ((1, "batch_kernels"), (0, "automatic"), (2, "forced"), (3, "four_lanes_per_pair")):
             if mode == 2 and Bs > 256:
                 continue  # one workgroup per pair at tens of thousands of pairs: milliseconds, nothing to learn
             eng.set_small_launch(mode)

@@ -113,6 +113,7 @@ struct DtwArgs {
     uint32_t dp_lanes;            // k_dtw_dp only: lanes per pair of the band kernel (4 / 8 / 16; 0 = default 8; 1 = k_dtw_dp_wave64)
     uint32_t *pair_count;         // k_dtw_cells only: [B] zeroed counters of finished pairs (the last one does the slot scan); may be NULL
     uint32_t cells_points;        // k_dtw_cells only: most band points of any pair of this store (dtw_cells_max_points; 0 = kernel not usable)
+    uint32_t tpl_neg2_ok;         // k_dtw_quad only: every coefficient of the store lies in [-16383, 16384], so -2 * coefficient fits s16 (checked when the store is set)
     uint32_t cells_literal;       // k_dtw_cells only: development hook "cells_literal" -- every pair takes the literal fallback walk
 };
 

@@ -573,7 +573,9 @@ int sr_set_dp_lanes(sr_engine *h, uint32_t lanes)
 int sr_set_small_launch(sr_engine *h, int mode)
 {
     if (!h) return fail(SR_ERR_BAD_ARG, "null engine");
-    if (mode < 0 || mode > 2) return fail(SR_ERR_BAD_ARG, "small-launch mode: 0 (automatic), 1 (never), 2 (whenever the store fits)");
+    if (mode < 0 || mode > 3)
+        return fail(SR_ERR_BAD_ARG, "small-launch mode: 0 (automatic), 1 (never), 2 (one workgroup per pair whenever the store fits), "
+                                    "3 (four lanes per pair whenever the store fits)");
     h->small_launch = mode;
     return SR_OK;
 }

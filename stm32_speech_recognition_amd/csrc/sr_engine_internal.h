@@ -108,7 +108,7 @@ struct sr_engine {
     uint32_t dp_lanes = 0;         // sr_set_dp_lanes: lanes per pair of the opt-in full-DP scorer (0 = default)
     uint32_t cells_points = 0;     // most band points of any pair of this store (k_dtw_cells' LDS; 0 = not usable)
     std::vector<uint32_t> cells_by_len;  // ... per template length, computed once (dtw_cells_max_points)
-    int small_launch = 0;          // sr_set_small_launch: 0 = k_dtw_cells for launches of a few hundred pairs, 1 = never, 2 = whenever it fits
+    int small_launch = 0;          // sr_set_small_launch: 0 = automatic (k_dtw_cells for a few hundred pairs, k_dtw_quad up to two rounds of the chip), 1 = never, 2 / 3 = k_dtw_cells / k_dtw_quad whenever it fits
     // scratch used when the caller does not ask for an intermediate (or passes host buffers)
     DevBuf<uint16_t> s_pcm;
     DevBuf<uint8_t> s_pack;   // sr_recognize_batch_packed12: the packed rows as uploaded, before k_unpack12

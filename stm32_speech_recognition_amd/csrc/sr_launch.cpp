@@ -1,6 +1,7 @@
 // Device-resident entry points of the C ABI (include/sr_engine.h): argument checks, the launch-argument blocks of the kernels,
 // and the sequencing of VAD -> frame kernel -> DTW -> slot scan on the caller's stream and the internal chunk streams.
 #include "sr_engine_internal.h"
+#include "sr_dtw_quad.h"
 
 using namespace sr;
 // ---- device-resident pipeline ---------------------------------------------------------------------
@@ -50,7 +51,7 @@ VadArgs vad_args(const sr_engine *h, const uint16_t *pcm, uint64_t stride, uint3
                         sr_vad_rec *vad, const sr_atap *atap_in, uint64_t *dbg)
 {
     // fewer captures than CUs: a workgroup of four waves per capture instead of one wave (k_vad_wide; same records)
-    const uint32_t wide = (h->small_launch == 2 || (h->small_launch == 0 && B < kVadWideBelow)) ? 1u : 0u;
+    const uint32_t wide = (h->small_launch == 2 || (h->small_launch != 1 && B < kVadWideBelow)) ? 1u : 0u;  // (mode 3 only forces the DTW form)
     return VadArgs{pcm, stride, buf_len, noise_len, h->atap_frm, h->cfg.max_frames, h->cfg.max_seg, B, vad, atap_in, dbg,
                    h->frame_len, h->v_durmin, h->s_durmax, wide};
 }
@@ -146,6 +147,7 @@ DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_
     a.dp_lanes = h->dp_lanes;
     a.pair_count = nullptr;
     a.cells_points = h->cells_points;
+    a.tpl_neg2_ok = h->tpl_staged_ok ? 1u : 0u;
     a.cells_literal = dev_hook(kHookCellsLiteral) != 0 ? 1u : 0u;
     return a;
 }
@@ -157,13 +159,28 @@ DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_
 // against 126 us for the batch kernel at any of these sizes; 256-frame captures against 100 templates of 192-320 frames (the
 // benchmark's shapes): 100 / 400 pairs 60 / 107 us against 215.  A pair costs in proportion to its band (~ frames^2), the
 // batch kernel's latency grows with the frames, so the automatic mode stops at 320 000 / max_frames pairs (2 689 / 1 000).
-static uint64_t small_launch_pairs(const DtwArgs &a) { return 320000u / (a.max_frames > 64 ? a.max_frames : 64u); }
+// Round 5: where the four-lanes-per-pair form (k_dtw_quad, below) can take over, one workgroup per pair only pays up to
+// 120 000 / max_frames pairs (1 008 / 375): 640 / 1 280 / 2 560 pairs take 44 / 65 / 114 us against a flat 49 us there.
+static uint64_t small_launch_pairs(const DtwArgs &a) { return (dtw_quad_fits(a) ? 120000u : 320000u) / (a.max_frames > 64 ? a.max_frames : 64u); }
 // returns true when the slot scan (argmin) has been done as well: k_dtw_cells with result records asked for and the utterances
 // b0 .. b0 + B of the call within the counters
+// Mid-sized launches: four lanes per pair (k_dtw_quad.hip).  Its workgroups hold PU x PK pairs with both sequences in LDS; a
+// "round" is what the chip holds at once (workgroups per CU by LDS, at most 8, x 256 CUs).  The batch kernel's time is flat up
+// to ~400 000 pairs (126 us at the firmware's shapes), a round of the quad kernel takes a third of that, so the automatic mode
+// hands it launches of up to two rounds (profiles/r05_small_launch_sweep.json).
+static uint64_t quad_launch_pairs(const DtwArgs &a)
+{
+    uint32_t pu = 0, pk = 0;
+    size_t lds = 0;
+    if (!dtw_quad_pick(a, &pu, &pk, &lds)) return 0;
+    const uint64_t per_cu = std::min<uint64_t>(8, 128 / ((lds + 1279) / 1280));
+    return 2 * 256 * per_cu * pu * pk;
+}
 // `owner` = the caller-level stream of the call (the counters belong to one caller stream, see sr_engine::cells_owner)
 bool launch_dtw_auto(sr_engine *h, DtwArgs &a, uint32_t b0, hipStream_t s, hipStream_t owner)
 {
-    if (h->small_launch != 1 && dtw_cells_fits(a) && (h->small_launch == 2 || (uint64_t)a.B * a.K <= small_launch_pairs(a))) {
+    const uint64_t pairs = (uint64_t)a.B * a.K;
+    if (h->small_launch != 1 && h->small_launch != 3 && dtw_cells_fits(a) && (h->small_launch == 2 || pairs <= small_launch_pairs(a))) {
         bool counters = a.results && (uint64_t)b0 + a.B <= kPairCounters;
         if (counters) {
             if (!h->cells_owner_set) {
@@ -175,6 +192,10 @@ bool launch_dtw_auto(sr_engine *h, DtwArgs &a, uint32_t b0, hipStream_t s, hipSt
         a.pair_count = counters ? h->s_pcnt.p + b0 : nullptr;
         launch_dtw_cells(a, s);
         return a.pair_count != nullptr;
+    }
+    if ((h->small_launch == 3 && dtw_quad_fits(a)) || (h->small_launch == 0 && pairs <= quad_launch_pairs(a))) {
+        launch_dtw_quad(a, s);
+        return false;
     }
     launch_dtw(a, s);
     return false;

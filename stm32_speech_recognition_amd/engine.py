@@ -310,8 +310,9 @@ class Engine:
 
     def set_small_launch(self, mode=0):
         """Small-launch forms of the kernels (four waves per capture in VAD, 4-frame workgroups in the frame kernel, one
-        workgroup per DTW pair + in-kernel slot scan, pinned host staging): 0 automatic by launch size, 1 never, 2 always
-        (DTW: whenever the in x mdl rectangle fits a workgroup's LDS).  Same results in every mode."""
+        workgroup per DTW pair + in-kernel slot scan, four lanes per DTW pair for mid-sized launches, pinned host staging):
+        0 automatic by launch size, 1 never, 2 always (DTW: one workgroup per pair whenever the in x mdl rectangle fits a
+        workgroup's LDS), 3 the four-lanes-per-pair DTW form whenever the sequences fit.  Same results in every mode."""
         self._check(self.L.sr_set_small_launch(self.h, C.c_int(mode)))
 
     def dtw_dp_dev(self, mfcc, scores, in_frames=None, vad=None, stream=None):

@@ -37,12 +37,12 @@ def oracle():
 
 def _dtw_all_modes(eng, im, inf):
     """sr_dtw_batch with the batch kernels (small-launch mode 1), with one workgroup per pair wherever the band fits
-    (mode 2, k_dtw_cells), in the automatic mode and with k_dtw_cells' literal fallback forced: scores and results must be
-    the same bytes; returns the first"""
+    (mode 2, k_dtw_cells), with four lanes per pair (mode 3, k_dtw_quad), in the automatic mode and with k_dtw_cells' literal
+    fallback forced: scores and results must be the same bytes; returns the first"""
     from stm32_speech_recognition_amd.engine import dev_hook
     eng.set_small_launch(1)
     sc, res = eng.dtw(im, inf)
-    for mode in (2, 0):
+    for mode in (2, 3, 0):
         eng.set_small_launch(mode)
         sc2, res2 = eng.dtw(im, inf)
         assert np.array_equal(sc, sc2), mode
@@ -441,8 +441,9 @@ def test_random_shapes_match_oracle(seed, maxf, K):
     assert np.array_equal(out["scores"].cpu().numpy().view(np.uint32), osc), (maxf, K, B)
     for f in ("best_tpl", "min_dis", "frm_num", "status"):
         assert np.array_equal(res[f], ores[f]), (f, maxf, K, B)
-    # the same call with one workgroup per pair (k_dtw_cells) wherever the in x mdl rectangle fits, and with it switched off
-    for mode in (2, 1):
+    # the same call with one workgroup per pair (k_dtw_cells) wherever the in x mdl rectangle fits, with four lanes per pair
+    # (k_dtw_quad), and with both switched off
+    for mode in (2, 3, 1):
         eng.set_small_launch(mode)
         out2 = eng.recognize_dev(d_pcm, eng.alloc_outputs(B, "cuda:0"))
         torch.cuda.synchronize()
@@ -695,7 +696,7 @@ def test_small_launch_at_the_benchmark_shapes():
     for nb in (1, len(fr)):
         x = pcm[:nb].contiguous()
         got = {}
-        for mode in (1, 0, 2):
+        for mode in (1, 0, 2, 3):
             eng.set_small_launch(mode)
             o = eng.alloc_outputs(nb, dev, mfcc=True, vad=True)
             ts = []
@@ -706,11 +707,55 @@ def test_small_launch_at_the_benchmark_shapes():
                 ts.append(time.perf_counter() - t0)
             got[mode] = (o["results"].cpu().numpy().copy(), o["scores"].cpu().numpy().copy())
             med[(nb, mode)] = float(np.median(ts[2:])) if nb == 1 else 0.0
-        for mode in (0, 2):
+        for mode in (0, 2, 3):
             assert np.array_equal(got[mode][0], got[1][0]) and np.array_equal(got[mode][1], got[1][1]), (nb, mode)
         assert (got[1][0].view(np.uint32).reshape(nb, 4)[:, 3] == 0).all()
     assert med[(1, 0)] * 1.5 < med[(1, 1)], med
     eng.close()
+
+
+def test_mid_sized_launch_takes_the_four_lane_form():
+    """256 captures against an 80-slot store at the firmware's shapes (20 480 pairs: far too many for one workgroup per pair,
+    far too few to fill the chip with one lane per pair): the automatic mode must pick k_dtw_quad, which shows in the DTW
+    kernel's own duration (hipEvents) -- at least 1.4x below the batch kernel's (measured 126 us for it at every size from
+    5 000 to 160 000 pairs) -- with identical scores and records, also for ragged lengths, gated-out and erased slots"""
+    from stm32_speech_recognition_amd import Engine
+    eng = Engine(max_frames=119, device=0)
+    bank = synth.word_bank(25)
+    rng = np.random.default_rng(14)
+    tfr = rng.integers(70, 120, 80)
+    tfr[7] = 30                                     # outside the 1/2..2x gate for most captures
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(80) % 25, tfr, seed=8, bank=bank, S=16000))
+    store, st = eng.train_store(tp, np.arange(80), n_slots=80)
+    store[11 * 4096:11 * 4096 + 2] = 0xFF           # an erased slot
+    eng.set_templates_store(store)
+    B = 256
+    fr = rng.integers(60, 119, B)
+    fr[:192] = 110
+    d = synth.make_utterances(rng.integers(0, 25, B), fr, seed=9, bank=bank, S=16000, device=torch.device("cuda", 0))
+    d[5] = 2048                                     # a silent capture: VAD fail, every score dis_err
+    got, dtw_us = {}, {}
+    for mode in (1, 3, 0):
+        eng.set_small_launch(mode)
+        o = eng.alloc_outputs(B, "cuda:0", mfcc=True, vad=True)
+        for _ in range(3):
+            eng.recognize_dev(d, o)
+        torch.cuda.synchronize()
+        eng.set_profiling(True)
+        for _ in range(10):
+            eng.recognize_dev(d, o)
+        torch.cuda.synchronize()
+        dtw_us[mode] = eng.stage_ms()["dtw"] * 1e3
+        eng.set_profiling(False)
+        got[mode] = (o["results"].cpu().numpy().copy(), o["scores"].cpu().numpy().copy())
+    eng.set_small_launch(0)
+    eng.close()
+    for mode in (3, 0):
+        assert np.array_equal(got[mode][0], got[1][0]) and np.array_equal(got[mode][1], got[1][1]), mode
+    sc = got[1][1].view(np.uint32)
+    assert (sc[:, 11] == ol.DIS_ERR).all() and (sc[5] == ol.DIS_ERR).all() and (sc[:192, 7] == ol.DIS_ERR).all()
+    print("DTW kernel us per launch (batch / four lanes per pair / automatic):", dtw_us)
+    assert dtw_us[0] * 1.4 < dtw_us[1] and dtw_us[3] * 1.4 < dtw_us[1], dtw_us
 
 
 def test_small_launch_soak():
@@ -1653,7 +1698,7 @@ def test_generic_front_end_random_configurations(seed):
     assert np.array_equal(out["scores"], osc), ekw
     for f in ("best_tpl", "min_dis"):
         assert np.array_equal(out["results"][f], ores[f]), (ekw, f)
-    for mode in (2, 1, 0):  # one workgroup per pair (k_dtw_cells, any feature width up to 16) / never / automatic
+    for mode in (2, 3, 1, 0):  # one workgroup per pair (k_dtw_cells, any feature width up to 16) / four lanes per pair / never / automatic
         eng.set_small_launch(mode)
         out2 = eng.recognize(pcm)
         assert np.array_equal(out2["scores"], osc) and out2["results"].tobytes() == out["results"].tobytes(), (ekw, mode)
