@@ -297,6 +297,10 @@ int sr_set_pipeline(sr_engine *h, uint32_t streams, uint32_t min_chunk, uint32_t
  *   host  sr_recognize_batch with at most 256 KB of captures: pinned staging, results written to pinned host memory.
  * Same results bit for bit (tests run the DTW / VAD / recognition cases in every mode).  One 16 000-sample capture against
  * 80 slots: 242 us -> 64 us per spch_recg call on an otherwise idle MI355X (profiles/, latency block of bench.py).
+ * The in-kernel slot scan of the one-workgroup-per-pair form counts finished pairs in per-engine counters, so it is available to
+ * ONE caller stream per engine -- the first that launches it (the internal stream of the host-buffer calls counts as one);
+ * small launches on any other stream of the same engine run the separate slot-scan kernel instead (same results, one more
+ * launch).  Calls on one engine from several host threads at once remain forbidden as everywhere in this API.
  * mode 0 = automatic (default), 1 = never (always the batch kernels), 2 = always (the one-workgroup-per-pair DTW form whenever
  * the rectangle fits), 3 = the four-lanes-per-pair DTW form whenever the sequences fit (VAD / MFCC / host side as in mode 0),
  * whatever the launch size: for tests and measurements. */

@@ -16,23 +16,27 @@ from stm32_speech_recognition_amd import Engine, synth  # noqa: E402
 
 
 def main():
-    Tl, S, Kl = 110, 16000, 80
-    eng = Engine(max_frames=119, device=0)
+    # default: the firmware's shapes; `bench`: the benchmark's (256-frame captures, 100 templates of 192-320 frames, 320-frame cap)
+    bench_shape = len(sys.argv) > 1 and sys.argv[1] == "bench"
+    Tl, S, Kl, cap = (256, synth.buf_len_for(320), 100, 320) if bench_shape else (110, 16000, 80, 119)
+    eng = Engine(max_frames=cap, device=0)
     bank = synth.word_bank(25)
     rng = np.random.default_rng(4)
-    tfr = rng.integers(70, 120, Kl)
+    tfr = rng.integers(192, 321, Kl) if bench_shape else rng.integers(70, 120, Kl)
     tp = synth.as_u16_numpy(synth.make_utterances(np.arange(Kl) % 25, tfr, seed=8, bank=bank, S=S))
-    store, st = eng.train_store(tp, np.arange(Kl), n_slots=Kl)
-    eng.set_templates_store(store)
-    n = 4096
+    stride = 4 + 24 * (cap + 1) if bench_shape else 4096
+    store, st = eng.train_store(tp, np.arange(Kl), n_slots=Kl, stride=stride)
+    assert (st == 0).all()
+    eng.set_templates_store(store, stride=stride)
+    n = 1024 if bench_shape else 4096
     dpcm = synth.make_utterances(rng.integers(0, 25, n), [Tl] * n, seed=9, bank=bank, S=S, device=torch.device("cuda", 0))
     rows = []
     ref = None
-    for Bs in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+    for Bs in ((1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024) if bench_shape else (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096)):
         o = eng.alloc_outputs(Bs, "cuda:0", mfcc=False, vad=False)
         row = {"B": Bs, "pairs": Bs * Kl}
         for mode, name in ((1, "batch_kernels"), (0, "automatic"), (2, "forced"), (3, "four_lanes_per_pair")):
-            if mode == 2 and Bs > 256:
+            if mode == 2 and Bs > (16 if bench_shape else 256):
                 continue  # one workgroup per pair at tens of thousands of pairs: milliseconds, nothing to learn
             eng.set_small_launch(mode)
             for _ in range(3):
@@ -57,7 +61,7 @@ def main():
                          "kernel_us": {k: round(sm[k] * 1e3, 1) for k in ("vad", "mfcc", "dtw", "argmin")},
                          "identical_to_batch_kernels": bool(np.array_equal(res, ref))}
         rows.append(row)
-    print(json.dumps({"shape": f"{S}-sample captures, {Tl}-frame words, {Kl} slots, 119-frame cap", "rows": rows}, indent=1))
+    print(json.dumps({"shape": f"{S}-sample captures, {Tl}-frame words, {Kl} slots, {cap}-frame cap", "rows": rows}, indent=1))
 
 
 if __name__ == "__main__":
