@@ -144,16 +144,35 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             wave_sync();
             uint32_t k5[4][4][2];
             load_tw32(s_tw5, lane, k5);
+            uint32_t nn[8];  // re^2 + im^2 of the lane's eight bins (one v_dot2_i32_i16 each, from the stored 16-bit halves)
 #pragma unroll
             for (int e3 = 0; e3 < 4; e3++) {
                 bfly_pk<true>(u[e3][0], u[e3][1], u[e3][2], u[e3][3], k5[e3][0][0], k5[e3][0][1], k5[e3][1][0],
                               k5[e3][1][1], k5[e3][2][0], k5[e3][2][1], k5[e3][3][0], k5[e3][3][1]);
-                // ---- |X|*10 and energy (MFCC.C:49-60, 128-133) on the stored 16-bit halves
-                {
-                    // re*re + im*im from the packed word; both bins' roots and the x10 in packed f32 operations (plain IEEE
-                    // multiplies and fused multiply-adds, see sqrt_rn_int)
-                    const f32x2 m = sqrt_rn_int2(f32x2{(float)sdot2z(u[e3][0], u[e3][0]), (float)sdot2z(u[e3][1], u[e3][1])}) *
+                nn[2 * e3] = (uint32_t)sdot2z(u[e3][0], u[e3][0]);
+                nn[2 * e3 + 1] = (uint32_t)sdot2z(u[e3][1], u[e3][1]);
+            }
+            // ---- |X|*10 and energy (MFCC.C:49-60, 128-133).  A QUIET frame -- every re^2 + im^2 of the frame <= kMagSmallMax, i.e.
+            // |X|*10 <= 1638 and E <= kMelFusedMaxE; decided for the whole wave, so the branch is uniform; 97.8 % of the benchmark's
+            // frames -- takes (u32)(v_sqrt_f32 * 10) for the magnitude (exact for every n <= 70 171 on gfx950, swept on the device
+            // by sr_mag_fast_sweep; 6.5 issue slots per bin) and the fused filterbank term below; any other frame the exactly
+            // corrected root (8.5 slots per bin; all 2^32 inputs certified, sr_dev.h sqrt_rn_int) and the literal filterbank form.
+            const uint32_t nmax = max(max(max(max(nn[0], nn[1]), nn[2]), max(max(nn[3], nn[4]), nn[5])), max(nn[6], nn[7]));
+            const bool quiet = __builtin_expect(__builtin_amdgcn_ballot_w64(nmax > kMagSmallMax) == 0, 1);
+            if (quiet) {
+#pragma unroll
+                for (int e3 = 0; e3 < 4; e3++) {
+                    const f32x2 m = f32x2{__builtin_amdgcn_sqrtf((float)(int)nn[2 * e3]), __builtin_amdgcn_sqrtf((float)(int)nn[2 * e3 + 1])} *
                                     f32x2{10.0f, 10.0f};
+                    const uint32_t m0 = cvt_u32(m.x), m1 = cvt_u32(m.y);
+                    buf[lane + 64 * e3] = umul24(m0, m0);
+                    buf[lane + 64 * e3 + 256] = umul24(m1, m1);
+                }
+            } else {
+#pragma unroll
+                for (int e3 = 0; e3 < 4; e3++) {
+                    // both bins' roots and the x10 in packed f32 operations (plain IEEE multiplies and fused multiply-adds, see sqrt_rn_int)
+                    const f32x2 m = sqrt_rn_int2(f32x2{(float)(int)nn[2 * e3], (float)(int)nn[2 * e3 + 1]}) * f32x2{10.0f, 10.0f};
                     const uint32_t m0 = cvt_u32(m.x), m1 = cvt_u32(m.y);  // < 2^19
                     buf[lane + 64 * e3] = umul24(m0, m0);
                     buf[lane + 64 * e3 + 256] = umul24(m1, m1);
@@ -166,12 +185,11 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
                 const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
                 uint32_t se = 0, so = 0;
-                // E*tri/100 (MFCC.C:139-161): while every E of the frame is <= kMelFusedMaxE (|X|*10 <= 1638) a term is ONE
-                // v_mul_hi_u32 of E << 4 with the per-bin multiplier (the shift shared by both poly-lines): 5 instructions
-                // per bin instead of 8 (mul_lo, mul_hi, shift, add per term).  A louder frame -- decided for the whole
-                // wave, so the branch is uniform -- takes the literal u32-wrapping form with tri recovered from the multiplier.
-                const uint32_t emax = max(max(max(max(e[0], e[1]), e[2]), max(max(e[3], e[4]), e[5])), max(e[6], e[7]));
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(emax > kMelFusedMaxE) == 0, 1)) {
+                // E*tri/100 (MFCC.C:139-161): in a quiet frame (every E <= kMelFusedMaxE, see above) a term is ONE v_mul_hi_u32 of
+                // E << 4 with the per-bin multiplier (the shift shared by both poly-lines): 5 instructions per bin instead of 8
+                // (mul_lo, mul_hi, shift, add per term).  A louder frame takes the literal u32-wrapping form with tri recovered
+                // from the multiplier.
+                if (quiet) {
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
                         const u32x4 me = s_tm[64 * c + lane], mo = s_tm[64 * (c + 2) + lane];

@@ -111,6 +111,25 @@ __global__ void __launch_bounds__(256) k_mel_term_sweep(uint32_t tri_lo, uint32_
     }
     if (n) atomicAdd(bad + blockIdx.y, n);
 }
+// diagnostics: the cheap magnitude form (v_sqrt_f32, x10, truncate) against the exact one for n in [0, n_max]
+__global__ void __launch_bounds__(256) k_mag_fast_sweep(uint32_t n_max, unsigned long long *bad, uint32_t *first_bad)
+{
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_max; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t n = (uint32_t)i;
+        const uint32_t want = cvt_u32(sqrt_rn_int((float)(int)n) * 10.0f);
+        const uint32_t got = mag10_small((float)(int)n);
+        if (want != got) {
+            c++;
+            atomicMin(first_bad, n);
+        }
+    }
+    if (c) atomicAdd(bad, c);
+}
+void launch_mag_fast_sweep(uint32_t n_max, unsigned long long *bad, uint32_t *first_bad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mag_fast_sweep, dim3(1024), dim3(256), 0, s, n_max, bad, first_bad);
+}
 void launch_mel_term_sweep(uint32_t tri_lo, uint32_t n_tri, uint32_t e_max, unsigned long long *bad, hipStream_t s)
 {
     if (!n_tri) return;

@@ -109,6 +109,16 @@ __device__ __forceinline__ float sqrt_rn_int(float f)
     return __builtin_fmaf(r, h, s0);
 }
 
+// (u32)(sqrtf(f) * 10) for SMALL integer-valued f (MFCC.C:56-58 on quiet bins): v_sqrt_f32 (within 1 ulp) instead of the
+// corrected reciprocal-root seed.  Only valid where sr_mag_fast_sweep has shown it equal to the exact form.
+__device__ __forceinline__ uint32_t mag10_small(float f)
+{
+    uint32_t r;
+    const float m = __builtin_amdgcn_sqrtf(f) * 10.0f;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(m));
+    return r;
+}
+
 // float -> u32 with the HARDWARE's semantics (v_cvt_u32_f32: truncation, NaN -> 0, saturation), stated as the instruction:
 // a C++ cast of NaN is undefined behaviour, and sqrt_rn_int(0) is NaN by design
 __device__ __forceinline__ uint32_t cvt_u32(float x)

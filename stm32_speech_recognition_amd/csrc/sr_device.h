@@ -166,6 +166,7 @@ void launch_unpack12(const void *packed, uint64_t row_bytes, uint16_t *out, uint
 void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
 // diagnostics: fused Mel filterbank term vs the reference's u32 expression, weights [tri_lo, tri_lo + n_tri), E <= e_max
 void launch_mel_term_sweep(uint32_t tri_lo, uint32_t n_tri, uint32_t e_max, unsigned long long *bad, hipStream_t s);
+void launch_mag_fast_sweep(uint32_t n_max, unsigned long long *bad, uint32_t *first_bad, hipStream_t s);
 // get_dis (DTW.C:45-62) for n frame pairs
 void launch_get_dis(const int16_t *a, const int16_t *b, uint32_t *out, uint32_t n, hipStream_t s);
 // dtw_limit (DTW.C:76-109) for n points with explicit statics

@@ -549,6 +549,25 @@ int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
     return SR_OK;
 }
 
+// diagnostics: the cheap magnitude form against the exact one, n in [0, n_max]: out[0] = mismatches, out[1] = first mismatching n
+int sr_mag_fast_sweep(sr_engine *h, uint32_t n_max, uint64_t out[2])
+{
+    if (!h || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (n_max > 0x7FFFFFFFu) return fail(SR_ERR_BAD_ARG, "n_max must be below 2^31");
+    ENTER_DEVICE(h);
+    int rc;
+    if ((rc = h->s_u32a.reserve(4))) return rc;
+    uint32_t init[4] = {0, 0, 0xFFFFFFFFu, 0};
+    HIP_TRY(hipMemcpy(h->s_u32a.p, init, sizeof init, hipMemcpyHostToDevice));
+    launch_mag_fast_sweep(n_max, (unsigned long long *)h->s_u32a.p, h->s_u32a.p + 2, nullptr);
+    HIP_TRY(hipGetLastError());
+    uint32_t back[4];
+    HIP_TRY(hipMemcpy(back, h->s_u32a.p, sizeof back, hipMemcpyDeviceToHost));
+    out[0] = (uint64_t)back[0] | ((uint64_t)back[1] << 32);
+    out[1] = back[2];
+    return SR_OK;
+}
+
 // diagnostics: k_mfcc's fused filterbank term against the reference's expression, see k_mel_term_sweep
 int sr_mel_term_sweep(sr_engine *h, uint32_t tri_lo, uint32_t tri_hi, uint32_t e_max, uint64_t *mismatches)
 {

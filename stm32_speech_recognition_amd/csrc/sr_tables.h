@@ -39,6 +39,11 @@ constexpr int kWinShift = 5;
 constexpr int32_t hamm_fused_multiplier(uint32_t h) { return (int32_t)((((uint64_t)h << 27) + 999u) / 1000u); }
 
 constexpr uint32_t kMelFusedMaxE = (1u << 28) / 100u;  // 2 684 354  (|X|*10 <= 1638)
+// re^2 + im^2 of a bin up to which (a) |X|*10 = (u32)(sqrtf(n)*10) <= 1638, hence E <= 1638^2 = 2 683 044 <= kMelFusedMaxE, and
+// (b) the uncorrected v_sqrt_f32 gives the same (u32)(sqrtf(n)*10) as the exact root (true for every n <= 70 171 on gfx950:
+// sr_mag_fast_sweep, repeated by every -m gpu run): 10*sqrt(26843) = 1638.38.  One test on n serves both fast forms of k_mfcc.
+constexpr uint32_t kMagSmallMax = 26843;
+static_assert(1638u * 1638u <= kMelFusedMaxE && 100ull * (kMagSmallMax + 1) < 1639ull * 1639ull, "quiet-frame bound");
 constexpr uint32_t kMelTriMax = 1599;                  // largest weight whose multiplier fits 32 bits
 constexpr uint32_t mel_fused_multiplier(uint32_t tri) { return (uint32_t)((((uint64_t)tri << 28) + 99u) / 100u); }
 

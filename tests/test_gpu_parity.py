@@ -2007,6 +2007,19 @@ def test_mel_term_fused_form_exhaustive(eng119):
     assert ctl.any()
 
 
+def test_magnitude_cheap_form_exhaustive(eng119):
+    """quiet frames of k_mfcc (every re^2 + im^2 <= 26 843) take (u32)(v_sqrt_f32(n) * 10) instead of the exactly corrected root:
+    equal to the exact form -- itself certified against the host's sqrtf over all 2^32 inputs -- for EVERY n up to 65 535 on
+    this device (the first difference is at n = 70 172); control: beyond that the cheap form does differ"""
+    import ctypes as C
+    from stm32_speech_recognition_amd.engine import _vp
+    out = np.zeros(2, np.uint64)
+    assert eng119.L.sr_mag_fast_sweep(eng119.h, C.c_uint32(65535), _vp(out)) == 0
+    assert out[0] == 0 and out[1] == 0xFFFFFFFF, out
+    assert eng119.L.sr_mag_fast_sweep(eng119.h, C.c_uint32((1 << 24) - 1), _vp(out)) == 0
+    assert out[0] > 0 and out[1] > 26843 * 2, out
+
+
 def test_filterbank_fused_and_literal_forms_match_oracle():
     """captures at gains that put frames on both sides of the fused form's bound (and far past it, into the u32 wrap of the
     reference's product): MFCC rows identical to the oracle's, and the oracle's own spectra confirm both forms were taken"""
