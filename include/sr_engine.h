@@ -341,7 +341,9 @@ int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
  * of a frame is <= 2 684 354 = floor(2^28 / 100). */
 int sr_mel_term_sweep(sr_engine *h, uint32_t tri_lo, uint32_t tri_hi, uint32_t e_max, uint64_t *mismatches);
 /* diagnostics: the cheap magnitude form the frame kernel may use on quiet frames -- (u32)(v_sqrt_f32((float)n) * 10) -- against the
- * exact one for every n in [0, n_max]: out[0] = number of n where they differ, out[1] = the smallest such n (0xFFFFFFFF: none) */
+ * exact one for every n in [0, n_max]: out[0] = number of n where they differ, out[1] = the smallest such n (0xFFFFFFFF: none).
+ * With bit 31 of n_max set the sweep compares what the DTW kernel's small-root form uses, floor(v_sqrt_f32((float)d)), with the
+ * exact (u32)sqrtf((float)d) of DTW.C:59 for every d in [0, n_max & 0x7fffffff]. */
 int sr_mag_fast_sweep(sr_engine *h, uint32_t n_max, uint64_t out[2]);
 /* diagnostics: per-utterance ballots of the VAD "loud" decision (VAD.C:164), 63 frames per 64-bit word, 16 words */
 int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,

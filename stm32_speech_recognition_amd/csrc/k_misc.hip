@@ -115,10 +115,16 @@ __global__ void __launch_bounds__(256) k_mel_term_sweep(uint32_t tri_lo, uint32_
 __global__ void __launch_bounds__(256) k_mag_fast_sweep(uint32_t n_max, unsigned long long *bad, uint32_t *first_bad)
 {
     unsigned long long c = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_max; i += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= (n_max & 0x7FFFFFFFu); i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t n = (uint32_t)i;
-        const uint32_t want = cvt_u32(sqrt_rn_int((float)(int)n) * 10.0f);
-        const uint32_t got = mag10_small((float)(int)n);
+        uint32_t want, got;
+        if (n_max & 0x80000000u) {  // development: floor of the plain v_sqrt_f32 against the exact (u32)sqrtf (DTW.C:59)
+            want = cvt_u32(sqrt_rn_int((float)n));
+            got = cvt_u32(__builtin_amdgcn_sqrtf((float)n));
+        } else {
+            want = cvt_u32(sqrt_rn_int((float)(int)n) * 10.0f);
+            got = mag10_small((float)(int)n);
+        }
         if (want != got) {
             c++;
             atomicMin(first_bad, n);

@@ -553,7 +553,6 @@ int sr_math_diag(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n)
 int sr_mag_fast_sweep(sr_engine *h, uint32_t n_max, uint64_t out[2])
 {
     if (!h || !out) return fail(SR_ERR_BAD_ARG, "null argument");
-    if (n_max > 0x7FFFFFFFu) return fail(SR_ERR_BAD_ARG, "n_max must be below 2^31");
     ENTER_DEVICE(h);
     int rc;
     if ((rc = h->s_u32a.reserve(4))) return rc;
