@@ -10,7 +10,7 @@
 // advances with their copies).  The chip is mostly idle at these sizes, so the step is made SHORT instead of narrow:
 //
 //   * the three candidates of a step (DTW.C:152-154: diag (x+1, y+1), up (x, y+1), right (x+1, y)) are evaluated by three
-//     lanes of a quad AT THE SAME TIME -- one dtw_limit, one get_dis incl. its exactly rounded root (sqrt_rn_int) per lane,
+//     lanes of a quad AT THE SAME TIME -- one dtw_limit (as the interval of its column), one get_dis incl. its exactly rounded root (sqrt_rn_int) per lane,
 //     no admissibility masks, no tie table, no bracket, no literal fallback: every lane simply has the reference's value of
 //     its candidate (dis_err outside the band).  The fourth lane repeats the diagonal one.
 //   * minimum AND move in one reduction: each lane forms key = (~cost << 2) | move with move = 3 (diag: x and y advance),
@@ -190,20 +190,18 @@ __global__ void __launch_bounds__(quad::kThreads) k_dtw_quad(const DtwArgs a, ui
             dis = cvt_u32(sqrt_rn_int((float)d0));  // DTW.C:146-148
         }
         uint32_t step = 1;
-        // dtw_limit (DTW.C:76-109) with the branches of its two tests turned into selects of the compared values; the integer
-        // expressions are the reference's
-        const int k1 = (int)in_n - 2 * (int)mdl_n, k2 = (int)mdl_n - 2 * (int)in_n;
+        const int c1s2 = 5 - ((int)in_n - 2 * (int)mdl_n), c2s = ((int)mdl_n - 2 * (int)in_n) - 3;  // dtw_limit's column bounds, below
         do {
             // all reads of the step are issued first, the band test runs while they are on their way
             const QRow<kWords> fa = lds_row<kWords>(qsm + (ra1 + umul24((uint32_t)px, coef_bytes(kWords))), qsm + (na1 + 4u * (uint32_t)px));
             const QRow<kWords> fb = lds_row<kWords>(qsm + (rb1 + umul24((uint32_t)py, coef_bytes(kWords))), qsm + (nb1 + 4u * (uint32_t)py));
-            // outside <=> A >= B || C <= D with the compared VALUES selected by the column (v_cndmask, no divergent branch):
-            //   x <  X1: A = y, B = 2x + 2           x >= X1: A = 2y + (in - 2 mdl), B = x + 4          (DTW.C:80-92)
-            //   x <  X2: C = 2y + 2, D = x           x >= X2: C = y + 4, D = 2x + (mdl - 2 in)          (DTW.C:94-106)
-            const bool lo1 = px < X1, lo2 = px < X2;
-            const int A = lo1 ? py : 2 * py + k1, Bv = lo1 ? 2 * px + 2 : px + 4;
-            const int Cv = lo2 ? 2 * py + 2 : py + 4, D = lo2 ? px : 2 * px + k2;
-            const bool out = (A >= Bv) | (Cv <= D);
+            // dtw_limit as the interval of its column (an algebraic identity over the integers, the form k_dtw_lds / k_dtw_cells /
+            // k_dtw_dp use): (px, py) is inside <=> lb(px) <= py < ub1(px),
+            //   ub1(x) = x < X1 ? 2x + 2 : (x + 5 - in + 2 mdl) >> 1      (DTW.C:80-92:  y >= 2x+2  /  2y + in - 2mdl >= x + 4)
+            //   lb(x)  = x < X2 ? x >> 1 : 2x + mdl - 2 in - 3            (DTW.C:94-106: 2y+2 <= x  /  y + 4 <= 2x + mdl - 2in)
+            const int ub1 = px < X1 ? 2 * px + 2 : (px + c1s2) >> 1;
+            const int lb = px < X2 ? px >> 1 : 2 * px + c2s;
+            const bool out = !((lb <= py) & (py < ub1));
             const uint32_t g = cvt_u32(sqrt_rn_int((float)dist2_rows<kWords, kNeg2>(fa, fb)));
             uint32_t kv;  // (~g << 2) | mv in one instruction
             asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(kv) : "v"(~g), "v"(mv));
