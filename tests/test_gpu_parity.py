@@ -758,6 +758,39 @@ def test_mid_sized_launch_takes_the_four_lane_form():
     assert dtw_us[0] * 1.4 < dtw_us[1] and dtw_us[3] * 1.4 < dtw_us[1], dtw_us
 
 
+def test_scratch_users_are_ordered_before_host_calls_reuse_the_scratch(golden):
+    """an asynchronous sr_recognize_batch_dev that was handed no buffers for its intermediates works in the
+    engine's scratch (s_vad, s_mfcc) on the CALLER's stream; a small host-buffer call right behind it runs on an internal
+    non-blocking stream and reuses the same scratch.  The engine now marks the end of such a call with an event and orders
+    every host-buffer entry point behind it.  Here: a 12 288-capture call on a non-blocking side stream (a few milliseconds
+    of kernels) with NO mfcc / vad buffers, directly followed -- no synchronisation -- by one-capture host calls (pinned path)
+    and a blocking-copy host call; all three must give what they give alone."""
+    from stm32_speech_recognition_amd import Engine
+    eng = Engine(max_frames=119, device=0)
+    eng.set_templates_store(golden["store"])
+    g = golden["pcm"]
+    dev = torch.device("cuda", 0)
+    big = torch.from_numpy(np.tile(g, (1024, 1)).view(np.int16)).to(dev)          # 12 288 captures
+    ref_big = eng.recognize_dev(big, eng.alloc_outputs(len(big), dev, mfcc=False, vad=False))
+    torch.cuda.synchronize()
+    want_sc, want_res = ref_big["scores"].clone(), ref_big["results"].clone()
+    want_small = eng.recognize(g[5:6])
+    side = torch.cuda.Stream(device=dev)
+    for it in range(6):
+        out = eng.alloc_outputs(len(big), dev, mfcc=False, vad=False)
+        out["scores"].zero_()
+        torch.cuda.synchronize()
+        eng.recognize_dev(big, out, stream=side.cuda_stream)                        # asynchronous, scratch intermediates
+        if it % 2 == 0:
+            small = eng.recognize(g[5:6])                                           # pinned small-call path, internal stream
+        else:
+            small = eng.recognize(np.tile(g[5:6], (300, 1)), want_mfcc=False, want_vad=False)  # > 256 captures: blocking-copy path
+        torch.cuda.synchronize()
+        assert torch.equal(out["scores"], want_sc) and torch.equal(out["results"], want_res), it
+        assert np.array_equal(small["scores"][0], want_small["scores"][0]) and small["results"][0] == want_small["results"][0], it
+    eng.close()
+
+
 def test_small_launch_soak():
     """thousands of small calls in the automatic mode against one run of the batch kernels: random sub-batches of 1-24 captures
     of random lengths, cut into chunks of 1 / 2 / 5 captures on three streams (several k_dtw_cells launches and their finished-
