@@ -115,33 +115,7 @@ __global__ void __launch_bounds__(64 * wide::kWaves) k_vad_wide(const VadArgs a)
         const uint32_t j = jb + lane;  // block index; frame f = j uses blocks j and j+1
         uint32_t A = 0, internal = 0, last = 0, cf = 0, c78 = 0;
         int pfo = -1;
-        if (mine && j <= F) {
-#pragma unroll
-            for (int t = 0; t < kHop / 8; t++) {
-                const uint4 q = row[(uint64_t)j * (kHop / 8) + t];
-                const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-                if (kSad) {  // v_sad_u16: |a.lo-b.lo| + |a.hi-b.hi| + c
-#pragma unroll
-                    for (int wdi = 0; wdi < 4; wdi++) A = __builtin_amdgcn_sad_u16(wds[wdi], mid2, A);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 8; s++) A += absdiff((wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF, mid);
-                }
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const int off = t * 8 + s;
-                    const uint32_t x = (wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF;
-                    const uint32_t c = (x >= a_thl) ? 2u : (x < b_thl ? 1u : 0u);
-                    if (off == kHop - 1) c78 = last;
-                    const bool nz = c != 0;
-                    internal += (nz && last != 0 && last != c) ? 1u : 0u;
-                    const bool first = nz && last == 0;
-                    cf = first ? c : cf;
-                    pfo = first ? off : pfo;
-                    last = nz ? c : last;
-                }
-            }
-        }
+        if (mine && j <= F) vad_block_summary<kHop, kSad>(row + (uint64_t)j * (kHop / 8), mid, mid2, a_thl, b_thl, A, internal, last, cf, c78, pfo);
         const uint32_t c80 = last;
         // the part without the carry: class of the last out-of-band sample in the wave's blocks <= j
         uint32_t R = c80;

@@ -14,6 +14,121 @@ constexpr int kVadWaves = 4;
 
 __device__ __forceinline__ uint32_t absdiff(uint32_t v, uint32_t mid) { return v > mid ? v - mid : mid - v; }
 
+
+// ---- summary of one block of kHop samples (VAD.C:121-157), with no state from earlier blocks --------------------------
+//   A        sum |x - mid|                                        (short-time magnitude, half a frame)
+//   internal band crossings among the block's own out-of-band samples (class changes 2 <-> 1, in-band samples skipped)
+//   last     class of the block's last out-of-band sample (0: none); c78: the same without the block's last sample
+//   cf, pfo  class and offset of its first out-of-band sample (0, -1: none)
+// Class of a sample: 2 above the band (x >= a_thl), 1 below (x < b_thl), 0 inside; "above" wins when both hold (u32
+// thresholds that wrapped, VAD.C:112-113).
+// Round 5: BIT-PARALLEL.  Per sample only two compares, each shifted into a mask with its carry (m = m + m + cc: v_cmp +
+// v_addc_co_u32) -- samples are taken from the block's end to its start, so that sample i lands on bit i.  Everything else
+// is arithmetic on the two masks (kHop bits each):
+//   * crossings 2 -> 1: a "below" sample whose nearest earlier out-of-band sample is "above".  That is exactly the carry
+//     of an adder with generate = above, propagate = in-band (kill = below): carries = ((G | P) + G) ^ (G | P) ^ G; the count
+//     is popcount(below & carries).  Likewise 1 -> 2 with the roles swapped.
+//   * first / last out-of-band sample: lowest / highest set bit of the two masks, compared with each other for the class.
+// (Round 4 walked the samples one by one with five carried values: 11.6 vector instructions per sample.)
+__device__ __forceinline__ uint32_t mask_lowest(const uint32_t *m, int nw)  // position of the lowest set bit, 0xFFFFFFFF: none
+{
+    uint32_t p = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = nw - 1; w >= 0; w--) p = m[w] ? (uint32_t)(32 * w + __builtin_ctz(m[w])) : p;
+    return p;
+}
+__device__ __forceinline__ uint32_t mask_highest1(const uint32_t *m, int nw)  // position of the highest set bit + 1, 0: none
+{
+    uint32_t p = 0;
+#pragma unroll
+    for (int w = 0; w < nw; w++) p = m[w] ? (uint32_t)(32 * w + 32 - __builtin_clz(m[w])) : p;
+    return p;
+}
+// one sample into the two masks: m = m + m + (compare), the compare on one 16-bit half of the word that holds two samples
+// (SDWA operand select), its result handed to the add as the carry: four instructions per sample.  (Left to the compiler:
+// v_cmp + v_cndmask per sample and a shift + v_or3 per pair, six per sample.)
+template <int kHalf>
+__device__ __forceinline__ void vad_sample_bits(uint32_t word, uint32_t a_thl, uint32_t b_thl, uint32_t &ma, uint32_t &mb)
+{
+    if (kHalf)
+        asm("v_cmp_ge_u32_sdwa vcc, %2, %3 src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_lt_u32_sdwa vcc, %2, %4 src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+            : "+v"(ma), "+v"(mb)
+            : "v"(word), "v"(a_thl), "v"(b_thl)
+            : "vcc");
+    else
+        asm("v_cmp_ge_u32_sdwa vcc, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_lt_u32_sdwa vcc, %2, %4 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+            : "+v"(ma), "+v"(mb)
+            : "v"(word), "v"(a_thl), "v"(b_thl)
+            : "vcc");
+}
+template <int kHop, bool kSad>
+__device__ __forceinline__ void vad_block_summary(const uint4 *blk, uint32_t mid, uint32_t mid2, uint32_t a_thl, uint32_t b_thl,
+                                                  uint32_t &A_out, uint32_t &internal, uint32_t &last, uint32_t &cf, uint32_t &c78,
+                                                  int &pfo)
+{
+    static_assert(kHop % 8 == 0, "blocks are read as 16-byte vectors");
+    constexpr int NW = (kHop + 31) / 32, NV = kHop / 8;
+    uint32_t wd[NV * 4];  // two samples per word
+    uint32_t A = 0;
+#pragma unroll
+    for (int t = 0; t < NV; t++) {
+        const uint4 q = blk[t];
+        wd[4 * t] = q.x, wd[4 * t + 1] = q.y, wd[4 * t + 2] = q.z, wd[4 * t + 3] = q.w;
+        if (kSad) {  // v_sad_u16: |a.lo-b.lo| + |a.hi-b.hi| + c
+#pragma unroll
+            for (int i = 0; i < 4; i++) A = __builtin_amdgcn_sad_u16(wd[4 * t + i], mid2, A);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) A += absdiff(wd[4 * t + i] & 0xFFFF, mid) + absdiff(wd[4 * t + i] >> 16, mid);
+        }
+    }
+    uint32_t ma[NW], mb[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int s = 31; s >= 0; s--) {
+            const int i = 32 * w + s;
+            if (i < kHop) {
+                if (i & 1) vad_sample_bits<1>(wd[i >> 1], a_thl, b_thl, a, b);
+                else vad_sample_bits<0>(wd[i >> 1], a_thl, b_thl, a, b);
+            }
+        }
+        ma[w] = a;
+        mb[w] = b & ~a;  // "above" wins
+    }
+    // band crossings inside the block: carries of the two (generate, propagate = in-band) additions, see above
+    uint32_t cnt = 0, ca = 0, cb = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t p = ~(ma[w] | mb[w]);
+        const uint32_t xa = ma[w] | p, xb = mb[w] | p;
+        const uint64_t sa = (uint64_t)xa + ma[w] + ca, sb = (uint64_t)xb + mb[w] + cb;
+        ca = (uint32_t)(sa >> 32);
+        cb = (uint32_t)(sb >> 32);
+        cnt += (uint32_t)__builtin_popcount(mb[w] & ((uint32_t)sa ^ xa ^ ma[w]));  // 2 -> 1
+        cnt += (uint32_t)__builtin_popcount(ma[w] & ((uint32_t)sb ^ xb ^ mb[w]));  // 1 -> 2
+    }
+    const uint32_t fa = mask_lowest(ma, NW), fb = mask_lowest(mb, NW);
+    pfo = (int)(fa < fb ? fa : fb);                       // -1: none
+    cf = fa < fb ? 2u : (fb < fa ? 1u : 0u);              // equal only when both are "none"
+    const uint32_t la = mask_highest1(ma, NW), lb = mask_highest1(mb, NW);
+    last = la > lb ? 2u : (lb > la ? 1u : 0u);
+    // the same without the block's last sample (VAD.C:131-157 evaluate the frame's first sample against the state BEFORE it)
+    ma[NW - 1] &= ~(1u << ((kHop - 1) & 31));
+    mb[NW - 1] &= ~(1u << ((kHop - 1) & 31));
+    const uint32_t la8 = mask_highest1(ma, NW), lb8 = mask_highest1(mb, NW);
+    c78 = la8 > lb8 ? 2u : (lb8 > la8 ? 1u : 0u);
+    A_out = A;
+    internal = cnt;
+}
+
 // kSad: |x - mid| sums of two samples per instruction (v_sad_u16).  Only valid for 16-bit mid values, which is what
 // noise_atap produces (a mean of u16 samples, VAD.C:41-47); the variant without it serves callers that hand their own
 // thresholds in (atap_in), which may hold anything.
@@ -92,33 +207,7 @@ __global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
         const uint32_t j = jb + lane;  // block index; frame f = j uses blocks j and j+1
         uint32_t A = 0, internal = 0, last = 0, cf = 0, c78 = 0;
         int pfo = -1;
-        if (j <= F) {
-#pragma unroll
-            for (int t = 0; t < kHop / 8; t++) {
-                const uint4 q = row[(uint64_t)j * (kHop / 8) + t];
-                const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-                if (kSad) {  // v_sad_u16: |a.lo-b.lo| + |a.hi-b.hi| + c
-#pragma unroll
-                    for (int wdi = 0; wdi < 4; wdi++) A = __builtin_amdgcn_sad_u16(wds[wdi], mid2, A);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 8; s++) A += absdiff((wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF, mid);
-                }
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const int off = t * 8 + s;
-                    const uint32_t x = (wds[s >> 1] >> (16 * (s & 1))) & 0xFFFF;
-                    const uint32_t c = (x >= a_thl) ? 2u : (x < b_thl ? 1u : 0u);
-                    if (off == kHop - 1) c78 = last;
-                    const bool nz = c != 0;
-                    internal += (nz && last != 0 && last != c) ? 1u : 0u;
-                    const bool first = nz && last == 0;
-                    cf = first ? c : cf;
-                    pfo = first ? off : pfo;
-                    last = nz ? c : last;
-                }
-            }
-        }
+        if (j <= F) vad_block_summary<kHop, kSad>(row + (uint64_t)j * (kHop / 8), mid, mid2, a_thl, b_thl, A, internal, last, cf, c78, pfo);
         const uint32_t c80 = last;
         // R(j) = class of the last out-of-band sample in blocks <= j
         uint32_t R = c80;
