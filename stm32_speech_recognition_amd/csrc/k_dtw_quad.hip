@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(quad::kThreads) k_dtw_quad(const DtwArgs a, ui
         const uint32_t na = ra + a.max_frames * coef_bytes(kWords), nb = rb + a.tpl_rows * coef_bytes(kWords);
         // the lane's candidate: move bits (bit 0: x advances, bit 1: y advances) and its point (px, py), 1-based
         const uint32_t mv = role == 1 ? 2u : role == 2 ? 1u : 3u;
+        const uint32_t mv4 = mv - 4u;  // see the key below
         const int dx = (int)(mv & 1u), dy = (int)(mv >> 1);
         int px = 1 + dx, py = 1 + dy;
         // The walk goes on while x < in && y < mdl (DTW.C:188), i.e. px < in + dx && py < mdl + dy.  Rows read: px - 1 <= in and
@@ -202,13 +203,26 @@ __global__ void __launch_bounds__(quad::kThreads) k_dtw_quad(const DtwArgs a, ui
             const int ub1 = px < X1 ? 2 * px + 2 : (px + c1s2) >> 1;
             const int lb = px < X2 ? px >> 1 : 2 * px + c2s;
             const bool out = !((lb <= py) & (py < ub1));
-            const uint32_t g = cvt_u32(sqrt_rn_int((float)dist2_rows<kWords, kNeg2>(fa, fb)));
-            uint32_t kv;  // (~g << 2) | mv in one instruction
-            asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(kv) : "v"(~g), "v"(mv));
+            // the candidate's key (~g << 2) | mv from the NEGATED root: Markstein's last fused step with both addends negated gives
+            // -sqrtf(d) (IEEE negation is exact), its signed truncation is -g, and (~g << 2) | mv = (-g << 2) + (mv - 4): one
+            // v_lshl_add_u32 instead of v_not + v_lshl_or.  (d = 0: the seed is inf, the result NaN, both conversions give 0.)
+            int ng;
+            {
+                const float f = (float)dist2_rows<kWords, kNeg2>(fa, fb);
+                const float y = __builtin_amdgcn_rsqf(f), s0 = f * y, h = 0.5f * y;
+                const float r = __builtin_fmaf(-s0, s0, f);
+                const float ns = __builtin_fmaf(-r, h, -s0);
+                asm("v_cvt_i32_f32 %0, %1" : "=v"(ng) : "v"(ns));
+            }
+            const uint32_t kv = ((uint32_t)ng << 2) + mv4;
             const uint32_t key = quad_max(out ? mv : kv);                 // DTW.C:152-184 in one reduction
             dis += (uint32_t)~((int)key >> 2);                            // + min (dis_err when all three are outside)
             px += (int)(key & 1u);
-            py += (int)__builtin_amdgcn_ubfe(key, 1, 1);
+            {
+                uint32_t b1;
+                asm("v_bfe_u32 %0, %1, 1, 1" : "=v"(b1) : "v"(key));
+                py += (int)b1;
+            }
             step++;  // (u16 in the reference: a walk has fewer than in + mdl <= 32 766 steps)
         } while (px < x_end && py < y_end);
         score = dis / step;  // DTW.C:191
