@@ -10,20 +10,23 @@
 // advances with their copies).  The chip is mostly idle at these sizes, so the step is made SHORT instead of narrow:
 //
 //   * the three candidates of a step (DTW.C:152-154: diag (x+1, y+1), up (x, y+1), right (x+1, y)) are evaluated by three
-//     lanes of a quad AT THE SAME TIME -- one dtw_limit (as the interval of its column), one get_dis incl. its exactly rounded root (sqrt_rn_int) per lane,
-//     no admissibility masks, no tie table, no bracket, no literal fallback: every lane simply has the reference's value of
-//     its candidate (dis_err outside the band).  The fourth lane repeats the diagonal one.
+//     lanes of a quad AT THE SAME TIME -- one dtw_limit (as the interval of its column), one get_dis incl. its exactly
+//     rounded root (sqrt_rn_int) per lane, no admissibility masks, no tie table, no bracket, no literal fallback: every
+//     lane simply has the reference's value of its candidate (dis_err outside the band).  The fourth lane repeats the
+//     diagonal one.
 //   * minimum AND move in one reduction: each lane forms key = (~cost << 2) | move with move = 3 (diag: x and y advance),
 //     2 (up: y), 1 (right: x); two v_max_u32 over the quad (DPP quad_perm) leave the largest key in all four lanes: the
 //     smallest cost, and among equal costs diag before up before right -- the order of DTW.C:168-184.  cost = ~(key >> 2)
 //     (arithmetic shift: the all-outside key (0 << 2 | move) gives dis_err = 2^32 - 1, which DTW.C:156-164 then adds, wrapping),
 //     and bits 0 / 1 of the key are the increments of x / y.
-//   * BOTH sequences are staged in LDS (32-byte rows: 12 coefficients | squared norm | pad; 48-byte rows up to 16
-//     coefficients) and every lane reads the two rows of its own candidate point afresh in every step -- two 16-byte reads
-//     each, no register copies, no exec-masked advance blocks, no template rows on their way from L2.
+//   * BOTH sequences are staged in LDS (24-byte coefficient rows + an array of squared norms: 28 bytes per row; 32 + 4 up to
+//     16 coefficients; template rows as -2 * coefficient when the store allows it) and every lane reads the two rows of its
+//     own candidate point afresh in every step -- three 8-byte reads + one 4-byte read each, no register copies, no
+//     exec-masked advance blocks, no template rows on their way from L2.
 //
-// A step is ~45 vector instructions on a chain of one LDS round trip, six dot products, one root and two DPP moves.  A
-// workgroup of 256 lanes walks PU utterances x PK templates (PU * PK <= 64 pairs), chosen so that two workgroups fit a CU.
+// A step is 43 vector instructions on a chain of one LDS round trip, six dot products, one root and two DPP moves.  A
+// workgroup of 256 lanes walks PU utterances x PK templates (PU * PK <= 64 pairs), the shape that keeps the most pairs
+// resident per CU (8 x 8 = 53 536 bytes = three workgroups per CU at the firmware's 119 / 120 rows).
 // Same arithmetic as k_dtw / k_dtw_gen (rows as packed pairs + norm, |a|^2 + |b|^2 - 2 a.b in the u32 ring): identical scores.
 #include <algorithm>
 
