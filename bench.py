@@ -20,6 +20,11 @@ batch into chunks on three internal streams.  Prints ONE JSON li
 `--batch 4096 --templates 10` is BASELINE configs[1] (a parity-test shape, not the headline metric).
 At N = 1 the default run also times BASELINE configs[1] and configs[4] (the extension front end, no reference
 counterpart) for a few steps each and reports them under `other_configs` -- never in `value`.
+The line carries `roofline` (dominant kernel against HBM as mandated, plus the fractions of the TIMED steps:
+`timed_step_frac`, `valu_frac`, `valu_frac_at_measured_clock`), `roofline_valu` (the binding ceiling, per workload shape from
+the committed PMC files) and `cpu_baseline` (the reference's own objects on the host cores, `cores_1` = one thread) with a
+parity flag; at N > 1 the baseline sample covers the first utterances of EVERY rank's shard, the GPU side read back from
+the gathered score matrix (`cpu_baseline.per_rank_sample`).
 """
 import argparse
 import json
