@@ -1,4 +1,4 @@
-"""Pipeline sweep at run time (sr_set_pipeline) for one workload: python profiles/experiments/pipe_tune_rt.py ref|ext [B]
+"""Pipeline sweep at run time (sr_set_pipeline) for one workload: python profiles/experiments/pipe_tune_rt.py ref|ext [B] [SxC,SxC,...]
 Prints ms per step for (streams, max_chunks) combinations; development aid, results in RESULTS.md."""
 import json, os, sys, time
 import numpy as np, torch
@@ -20,6 +20,8 @@ def main():
     out = eng.alloc_outputs(B, dev, mfcc=True, vad=True)
     res = {}
     combos = [(1, 1), (2, 8), (2, 12), (3, 6), (3, 9), (3, 12), (3, 15), (3, 18), (3, 24), (4, 8), (4, 12), (4, 16), (4, 24), (2, 16), (3, 12)]
+    if len(sys.argv) > 3:
+        combos = [tuple(int(v) for v in c.split("x")) for c in sys.argv[3].split(",")]
     for st, mc in combos:
         eng.set_pipeline(streams=st, min_chunk=max(1, B // 64), max_chunks=mc)
         for _ in range(2):

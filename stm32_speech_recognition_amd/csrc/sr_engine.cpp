@@ -446,7 +446,10 @@ static int upload_templates(sr_engine *h, const std::vector<int16_t> &m, const s
         const size_t room = fixed < budget ? (budget - fixed) / sizeof(uint32_t) : 0;
         if (h->cells_points > room) h->cells_points = room >= 4096 ? (uint32_t)room : 0u;
     }
-    if (!h->pipe_user_set) h->pipe_max_chunks = K >= 256 ? 6 : 12;
+    // Large stores: the DTW is most of a step (70 % at K = 500), every chunk adds one drain of its long workgroups, and there
+    // is little left to overlap it with: one chunk per stream.  Measured at 65 536 x 500 (profiles/experiments/RESULTS.md):
+    // 3 streams x 3 chunks 44.4-44.6 ms, x 6: 44.8-44.9, x 12: 45.2; x 4 (one chunk left over on one stream): 45.4.
+    if (!h->pipe_user_set) h->pipe_max_chunks = K >= 256 ? h->pipe_streams : 12;
     h->K = K;
     h->tpl_rows = rows;
     h->tpl_stride = rows * nc;

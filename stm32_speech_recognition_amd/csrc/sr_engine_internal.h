@@ -148,7 +148,7 @@ struct sr_engine {
                                            // 3 -> 28.2, 4 -> 30.0 ms per 65 536 utterances (1 -> 32.0)
     uint32_t pipe_min_chunk = 4096;        // sr_set_pipeline min_chunk: utterances per chunk at least (smaller chunks lose more than they gain:
                                            // 4 096 x 10 as two chunks of 2 048: 1.93 ms per step, as one chunk 1.63)
-    uint32_t pipe_max_chunks = 12;         // chunks per call at most (sr_set_pipeline); 6 for large stores, see upload_templates
+    uint32_t pipe_max_chunks = 12;         // chunks per call at most (sr_set_pipeline); one per stream for large stores, see upload_templates
     bool pipe_user_set = false;            // sr_set_pipeline was called: the engine no longer adapts the chunk count to the store
     // profiling (sr_set_profiling / sr_get_stage_ms): events recorded since profiling was switched on
     bool profiling = false;

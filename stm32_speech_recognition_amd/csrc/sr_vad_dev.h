@@ -133,7 +133,7 @@ __device__ __forceinline__ void vad_block_summary(const uint4 *blk, uint32_t mid
 // noise_atap produces (a mean of u16 samples, VAD.C:41-47); the variant without it serves callers that hand their own
 // thresholds in (atap_in), which may hold anything.
 template <int kFrameLen, int kHop, bool kSad>  // 160/80 = the reference (VAD.H:5-8); 320/160 = the 16 kHz extension
-__global__ void __launch_bounds__(64 * kVadWaves) k_vad(const VadArgs a)
+__global__ void __launch_bounds__(64 * kVadWaves) __attribute__((amdgpu_waves_per_eu(1, kHop > 80 ? 4 : 8))) k_vad(const VadArgs a)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t b = blockIdx.x * kVadWaves + (threadIdx.x >> 6);
