@@ -269,7 +269,8 @@ int sr_allgather_scores(void *nccl_comm, const uint32_t *d_scores, uint32_t *d_a
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * sr_recognize_batch_dev cuts a large batch into chunks (at least min_chunk = 4096 utterances each, at most
- * max_chunks = 12) and runs them on streams = 3 (max 4) internal streams forked from / joined to the
+ * max_chunks = 12; one chunk per stream once the store holds 256 templates or more) and runs them on streams = 3 (max 4)
+ * internal streams forked from / joined to the
  * caller's stream, so each kernel is launched once per chunk and kernels of different chunks overlap
  * (sr_set_pipeline changes the three numbers; streams = 1 keeps everything on the caller's stream).  The library reads
  * no tuning knob from the environment (the only environment variable it honours is SR_RCCL_LIBRARY, the path of the
