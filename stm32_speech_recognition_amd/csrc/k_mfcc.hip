@@ -55,10 +55,6 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         for (int c = 0; c < 8; c++) s_tw3[lane * 8 + c] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
     }
     if (w == 1 % kMfccWaves) store_tw32(s_tw5, lane, tw.s5);
-    __syncthreads();
-    int hamm_m[3];  // window weights of the lane's three samples as fused multipliers (sr_tables.h hamm_fused_multiplier)
-#pragma unroll
-    for (int k = 0; k < 3; k++) hamm_m[k] = (lane + 64 * k < kFrameLen) ? hamm_fused_multiplier(a.t.hamm[lane + 64 * k]) : 0;
     // triangle weights of bins 8*lane .. 8*lane+7 of both poly-lines as fused multipliers ceil(tri * 2^28 / 100)
     // (sr_tables.h mel_fused_multiplier), parked in LDS as lane-contiguous 16-byte chunks like the pass-5 coefficients
     // (chunk c of lane l at s_tm[64 c + l]: even 0-3, even 4-7, odd 0-3, odd 4-7; conflict-free ds_read_b128, and LDS
@@ -70,6 +66,10 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             s_tm[64 * (c + 2) + lane] = *(const u32x4 *)(a.t.tri_odd_m + 8 * lane + 4 * c);
         }
     }
+    __syncthreads();  // every table above is written by ONE wave and read by all of them: nothing shared is written below this line
+    int hamm_m[3];  // window weights of the lane's three samples as fused multipliers (sr_tables.h hamm_fused_multiplier)
+#pragma unroll
+    for (int k = 0; k < 3; k++) hamm_m[k] = (lane + 64 * k < kFrameLen) ? hamm_fused_multiplier(a.t.hamm[lane + 64 * k]) : 0;
     // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
     int f_lo = 0, f_hi = 0;
     if (lane < kMel) {

@@ -831,6 +831,58 @@ def test_small_launch_soak():
     eng.close()
 
 
+def test_concurrent_device_and_host_calls_soak():
+    """Two calls of one engine in flight at once, for ~15 s: a device call of 1 229-2 048 captures with the caller's own
+    buffers on a side stream (one launch of each batch kernel, every frame-kernel workgroup lives for exactly one work
+    item) and, not synchronised with it, a one-capture host call on the engine's internal stream (k_vad_wide, k_mfcc<1>,
+    k_dtw_cells).  Every score, record, MFCC row and VAD record of the device call must be what the batch gives alone.
+    Round 5: this arrangement found a missing barrier in k_mfcc (the filterbank multipliers in LDS were written by one wave
+    AFTER the workgroup's last barrier; a wave that reached its first frame's filterbank before them read what the
+    previous workgroup had left there -- the same values as long as that was another k_mfcc workgroup, anything once the
+    concurrent call's kernels had used the CU): one wrong MFCC row per ~6 000 calls."""
+    import time
+    from stm32_speech_recognition_amd import Engine
+    eng = Engine(max_frames=119, device=0)
+    bank = synth.word_bank(25)
+    rng = np.random.default_rng(12)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(80) % 25, rng.integers(40, 120, 80), seed=8, bank=bank, S=16000))
+    store, st = eng.train_store(tp, np.arange(80), n_slots=80)
+    eng.set_templates_store(store)
+    n = 2048
+    dev = torch.device("cuda", 0)
+    dpcm = synth.make_utterances(rng.integers(0, 25, n), rng.integers(30, 119, n), seed=9, bank=bank, S=16000, device=dev)
+    hpcm = dpcm.cpu().numpy().view(np.uint16)
+    eng.set_small_launch(1)
+    o = eng.recognize_dev(dpcm, eng.alloc_outputs(n, dev, mfcc=True, vad=True))
+    torch.cuda.synchronize()
+    want = {k: o[k].clone() for k in ("results", "scores", "mfcc", "vad")}
+    er = want["results"].cpu().numpy().view(np.uint32).reshape(n, 4)
+    eng.set_small_launch(0)
+    eng.set_pipeline(streams=3, min_chunk=4096, max_chunks=12)
+    side = torch.cuda.Stream(device=dev)
+    budget = float(os.environ.get("SR_SOAK_SECONDS", "20"))
+    t0, calls = time.time(), 0
+    while time.time() - t0 < budget:
+        nb = int(rng.integers(1229, 2049))
+        b0 = int(rng.integers(0, n - nb + 1))
+        oo = eng.alloc_outputs(nb, dev, mfcc=True, vad=True)
+        eng.recognize_dev(dpcm[b0:b0 + nb], oo, stream=side.cuda_stream)
+        b = int(rng.integers(0, n))
+        r = eng.recognize(hpcm[b:b + 1], want_scores=False, want_mfcc=False, want_vad=False)["results"]
+        torch.cuda.synchronize()
+        calls += 1
+        # (a wrong MFCC row shows in most of its utterance's 80 scores; the rows themselves are only looked at to say where)
+        if not (torch.equal(oo["scores"], want["scores"][b0:b0 + nb]) and torch.equal(oo["results"], want["results"][b0:b0 + nb])):
+            where = {}
+            for k in ("vad", "mfcc", "scores", "results"):
+                d = (oo[k].reshape(nb, -1) != want[k][b0:b0 + nb].reshape(nb, -1)).any(1)
+                where[k] = torch.nonzero(d).ravel()[:4].tolist()
+            raise AssertionError(f"call {calls}: the device call differs at utterances {where} (nb {nb}, b0 {b0})")
+        assert (r["best_tpl"][0], r["min_dis"][0], r["frm_num"][0], r["status"][0]) == tuple(er[b]), (calls, b)
+    assert calls > 200, calls
+    eng.close()
+
+
 def test_small_launch_forms_are_taken(golden):
     """one capture against an 80-slot store at the firmware's shapes: the automatic mode must pick the small-launch kernel forms
     (k_vad_wide, k_mfcc<1>, k_dtw_cells + in-kernel slot scan), which shows as at least 1.5x fewer microseconds per call than
