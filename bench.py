@@ -86,6 +86,13 @@ def parse_args(argv=None):
                     help="greedy = the reference's dtw() (the metric); dp = time ONLY the opt-in NON-REFERENCE full-DP scorer "
                          "(sr_dtw_dp_batch_dev) on the same features -- a side measurement, never the headline metric")
     ap.add_argument("--dp-lanes", type=int, default=0, help="--scorer dp: lanes per pair (0 default = 8; 4, 8, 16; 1 = first version)")
+    ap.add_argument("--gain", type=float, default=1.0,
+                    help="speech amplitude factor of the synthetic captures (synth.make_utterances): 1.0 = sinusoids of amplitude 64-300 "
+                         "ADC codes (the headline since round 1), 2.4 = SURVEY.md 8(d)'s 200-600 (154-720).  The frame kernel's cost "
+                         "depends on it (three magnitude / filterbank tiers, DESIGN.md 3.2), so every line carries `workload_stats`")
+    ap.add_argument("--exchange", choices=["scores", "results"], default="scores",
+                    help="N > 1: what the one collective of a step gathers -- the u32 score matrix [B, K] (north_star; 26 MB per rank "
+                         "at K = 100) or the 16-byte result records [B] (1 MB per rank; SURVEY.md 8(e) names both)")
     ap.add_argument("--other-scale", type=int, default=1,
                     help="tests: divide the other_configs batches by this and run them whatever the headline shape is")
     return ap.parse_args(argv)
@@ -170,12 +177,12 @@ def workload_setup(workload, Kt):
     return 1, {}, Kt or K_DEFAULT, min(N_WORDS_DEFAULT, Kt or K_DEFAULT)
 
 
-def make_templates(eng, bank, Kt, n_words, rate, dev):
+def make_templates(eng, bank, Kt, n_words, rate, dev, gain=1.0):
     """Kt synthetic words through the SAME front end (main.c:121-138 save_mdl) -> dense template set on the host"""
     rng = np.random.default_rng(2026)
     tfr = rng.integers(192, 321, Kt)
     tpcm = synth.make_utterances(np.arange(Kt) % n_words, tfr, seed=77, bank=bank, S=synth.buf_len_for(320, rate), device=dev,
-                                 rate=rate)
+                                 rate=rate, gain=gain)
     tvad, tmf = eng.features_dev(tpcm)
     torch.cuda.synchronize(dev)
     tv = vad_from_torch(tvad)
@@ -246,7 +253,7 @@ class ClockSampler:
 FORCE_DIST = False  # test hook SR_BENCH_FORCE_DIST=1: initialise the process group and run the exchange even at N = 1
 
 
-def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
+def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist, gain=1.0, exchange="scores"):
     """K timed steps of one workload on this rank's GPU (barrier + synchronize on both sides, max over ranks), then an
     untimed isolated pass (whole batch as one chunk on one stream) for the per-kernel durations.  Returns a dict."""
     rate, eng_cfg, Kt, n_words = workload_setup(workload, Kt)
@@ -254,18 +261,20 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     S = synth.buf_len_for(T, rate)
     eng = Engine(max_frames=MAX_FRAMES, device=local_rank, **eng_cfg)
     bank = synth.word_bank(n_words)
-    tm, tfr, rng = make_templates(eng, bank, Kt, n_words, rate, dev)
+    tm, tfr, rng = make_templates(eng, bank, Kt, n_words, rate, dev, gain)
     eng.set_templates_dense(tm, tfr.astype(np.uint32))
 
     # ---- this rank's shard of utterances, generated straight into HBM -------------------------------
     lo, hi = du.shard_bounds(world * B, world, rank)  # weak scaling: B utterances per rank
     words = torch.from_numpy(rng.integers(0, n_words, world * B))[lo:hi]
-    pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev, rate=rate)
+    pcm = synth.make_utterances(words, [T] * B, seed=1000 + rank, bank=bank, S=S, device=dev, rate=rate, gain=gain)
     # N > 1: two output sets, so the all-gather of step i (RCCL stream) overlaps the kernels of step i+1
     use_dist = dist is not None
     outs = [eng.alloc_outputs(B, dev, mfcc=True, vad=True) for _ in range(2 if use_dist else 1)]
     out = outs[0]
-    xchg = du.ScoreExchange(world, [torch.empty(world * B, Kt, dtype=torch.int32, device=dev) for _ in outs],
+    # the path's one exchange step gathers the score matrix (north_star) or, --exchange results, the 16-byte result records
+    xkey, xcols = ("scores", Kt) if exchange == "scores" else ("results", 4)
+    xchg = du.ScoreExchange(world, [torch.empty(world * B, xcols, dtype=torch.int32, device=dev) for _ in outs],
                             force=FORCE_DIST) if use_dist else None
     n_step = [0]
 
@@ -275,8 +284,8 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
         if xchg is not None:
             xchg.reserve(j)  # the gather that read outs[j]["scores"] two steps ago is ordered before the kernels
         eng.recognize_dev(pcm, outs[j])
-        if xchg is not None:  # the path's one exchange step: all-gather of per-template scores over xGMI
-            xchg.launch(j, outs[j]["scores"])
+        if xchg is not None:  # the path's one exchange step: all-gather of per-template scores (or result records) over xGMI
+            xchg.launch(j, outs[j][xkey])
 
     def finish():
         if xchg is not None:
@@ -302,7 +311,7 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     dt = du.max_over_ranks(dt, dev, 2 if (use_dist and world == 1) else world)
     stage = eng.stage_ms()  # hipEvent timings of the timed steps, each kernel on the stream it was launched on
     eng.set_profiling(False)
-    exchange = None
+    exchange_kind, exchange = exchange, None
     if use_dist:
         # diagnostics of the path's one exchange step (outside the timed region): every rank's own wall time of the timed
         # steps, the all-gather ALONE on an otherwise idle GPU (hipEvents on the current stream around a synchronous
@@ -315,13 +324,14 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
             dist.barrier()
             torch.cuda.synchronize()
             e0.record()
-            dist.all_gather_into_tensor(xchg.gathered[0], outs[0]["scores"].contiguous())
+            dist.all_gather_into_tensor(xchg.gathered[0], outs[0][xkey].contiguous())
             e1.record()
             torch.cuda.synchronize()
             ag.append(e0.elapsed_time(e1))
         exchange = {"backend": dist.get_backend(), "ranks_in_communicator": dist.get_world_size(),
+                    "gathers": "score matrix u32 [B, K]" if exchange_kind == "scores" else "result records, 16 bytes per utterance",
                     "step_ms_per_rank": per_rank, "allgather_ms": float(np.median(ag)),
-                    "allgather_bytes_per_rank_out": int(world * B * Kt * 4),
+                    "allgather_bytes_per_rank_out": int(world * B * xcols * 4),
                     "exposed_allgather_ms": max(0.0, dt / steps * 1e3 - stage["total"]),
                     "note": "allgather_ms: the collective alone (idle GPU, median of 3); exposed: wall time per step minus the "
                             "engine's fork->join kernel time of a step = what the double-buffered exchange does not hide "
@@ -345,7 +355,7 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
     acc = float((res["best_tpl"] % n_words == words.numpy()).mean())
     if xchg is not None:  # the gathered matrix holds every rank's scores in global utterance order
         g = xchg.gathered[0][rank * B:(rank + 1) * B]
-        assert torch.equal(g, out["scores"]), "all-gather did not return this rank's shard in place"
+        assert torch.equal(g, out[xkey].view(B, xcols)), "all-gather did not return this rank's shard in place"
     sample_pcm = None
     if xchg is not None:  # first PER_RANK_PARITY_N capture buffers of every rank's shard, for rank 0's CPU parity check
         ns = min(PER_RANK_PARITY_N, B)
@@ -353,17 +363,40 @@ def measure(workload, B, Kt, steps, warmup, rank, world, local_rank, dist):
         # as bytes: the 16-bit sample type is not a collective dtype of every backend (gloo refuses it)
         dist.all_gather_into_tensor(sample_pcm.view(torch.uint8), pcm[:ns].contiguous().view(torch.uint8))
     return dict(dt=dt, stage=stage, stage_iso=stage_iso, acc=acc, eng=eng, pcm=pcm, out=out, tm=tm, tfr=tfr, S=S, rate=rate,
-                eng_cfg=eng_cfg, K=Kt, n_words=n_words, sclk=clk.summary(), exchange=exchange,
+                eng_cfg=eng_cfg, K=Kt, n_words=n_words, sclk=clk.summary(), exchange=exchange, gain=gain, exchange_kind=xkey,
                 gathered=xchg.gathered[0] if xchg is not None else None, sample_pcm=sample_pcm)
 
 
-def workload_name(workload, B, Kt):
+SURVEY_GAIN = 2.4        # synth.make_utterances gain that gives SURVEY.md 8(d)'s sinusoid amplitudes (200-600: 64-300 x 2.4 = 154-720)
+WORKLOAD_STATS_N = 32    # capture buffers whose frames are sorted into the frame kernel's tiers (host-side diagnostic)
+
+
+def workload_stats(host, eng_cfg, gain):
+    """What the timed workload looks like to the frame kernel (host-side diagnostic on the first captures of the batch; part of
+    the CPU legs, absent with --no-cpu-baseline): the speech amplitude the generator was asked for and the share of frames in
+    each of k_mfcc's magnitude / filterbank tiers (QUIET = every re^2 + im^2 of the frame <= 26 843, MID <=
+    70 171, LOUD beyond), counted on the spectra of the CPU oracle (the product is not involved).  The extension front end has
+    one code path, its fractions are reported for comparison only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    orc = ol.Oracle(max_frames=MAX_FRAMES, **eng_cfg)
+    t = orc.frame_tiers(host)
+    return {"gain": gain, "speech_amplitude": [round(64 * gain, 1), round(300 * gain, 1)],
+            "speech_amplitude_note": "per-sinusoid amplitude range in ADC codes (three chirped sinusoids x envelope 0.55-1.0 + N(0,30)); "
+                                     "SURVEY.md 8(d) specifies 200-600 = gain 2.4",
+            "quiet_frame_fraction": t["quiet"], "mid_frame_fraction": t["mid"], "loud_frame_fraction": t["loud"],
+            "frames_counted": t["frames"], "captures_counted": int(len(host)),
+            "tiers_apply": not eng_cfg}
+
+
+def workload_name(workload, B, Kt, gain=1.0):
+    amp = "" if gain == 1.0 else (f", speech amplitude x{gain:g}" + (" = SURVEY.md 8(d)'s 200-600" if gain == SURVEY_GAIN else ""))
     if workload == "ext":
         return (f"BASELINE configs[4] EXTENSION (no reference counterpart): 16 kHz / 512-pt / 40 Mel, batch={B} utterances x "
-                f"{Kt} templates per GPU, 256 frames")
+                f"{Kt} templates per GPU, 256 frames" + amp)
     idx = 2 if (B, Kt) == (65536, 100) else 1 if (B, Kt) == (4096, 10) else "-"
     return (f"BASELINE configs[{idx}]: batch={B} utterances x {Kt} templates per GPU, 256 frames, 12-coef MFCC, 8 kHz "
-            "25360-sample capture buffers")
+            "25360-sample capture buffers" + amp)
 
 
 def mfcc_bytes(rate):
@@ -371,20 +404,22 @@ def mfcc_bytes(rate):
     return mfcc_kernel_bytes_per_utt(T, C) if rate == 1 else 2 * (160 * (T - 1) + 320 + 1) + 2 * T * C + 48
 
 
-def other_config(workload, B, Kt, steps, local_rank, cpu_n):
+def other_config(workload, B, Kt, steps, local_rank, cpu_n, gain=1.0):
     """one `other_configs` entry: a parity-test shape of BASELINE.json timed for a few steps under the same rules as the
     headline (inputs resident, barrier-free at N = 1, synchronize on both sides) + a CPU parity check on a sample"""
-    m = measure(workload, B, Kt, steps, 1, 0, 1, local_rank, None)
+    m = measure(workload, B, Kt, steps, 1, 0, 1, local_rank, None, gain=gain)
     by = mfcc_bytes(m["rate"])
     iso = m["stage_iso"]
-    e = {"workload": workload_name(workload, B, m["K"]), "value": B * steps / m["dt"], "unit": "utterances/s",
+    e = {"workload": workload_name(workload, B, m["K"], gain), "value": B * steps / m["dt"], "unit": "utterances/s",
          "ms_per_step": m["dt"] / steps * 1e3, "steps": steps, "warmup": 1,
          "kernel_ms_isolated": {k: iso[k] for k in ("vad", "mfcc", "dtw", "argmin", "total")},
          "roofline_hbm_frac_dominant_kernel": by * B / (iso["mfcc"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
          "top1_word_accuracy": m["acc"]}
-    rv, rv_stale = valu_roofline(valu_pmc_file(workload, B, m["K"]), B, m["stage"]["total"], m.get("sclk"))
+    rv, rv_stale = valu_roofline(valu_pmc_file(workload, B, m["K"], gain), B, m["stage"]["total"], m.get("sclk"))
     e["roofline_valu"], e["roofline_valu_stale"] = rv, rv_stale
+    e["sclk"] = m.get("sclk")
     if cpu_n:
+        e["workload_stats"] = workload_stats(synth.as_u16_numpy(m["pcm"][:WORKLOAD_STATS_N]), m["eng_cfg"], gain)
         cb = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], min(cpu_n, B), m["eng_cfg"])
         e["parity_on_sample"] = {"identical": bool(cb["gpu_results_identical_on_sample"] and
                                                    cb.get("port", cb)["gpu_results_identical_on_sample"]),
@@ -686,7 +721,8 @@ def run_rank(args):
         out_stream.write(json.dumps(line) + "\n")
         out_stream.flush()
         return 0
-    m = measure(args.workload, B, args.templates, args.steps, args.warmup, rank, world, local_rank, dist)
+    m = measure(args.workload, B, args.templates, args.steps, args.warmup, rank, world, local_rank, dist, gain=args.gain,
+                exchange=args.exchange)
     if rank == 0:
         line = headline(args, m, world, backend)
         if FORCE_DIST:
@@ -699,8 +735,11 @@ def run_rank(args):
             n0 = min(args.cpu_sample, 1024, B)
             hosts = [synth.as_u16_numpy(m["pcm"][:n0])] + [sp[r * ns:(r + 1) * ns] for r in range(1, world)]
             line["cpu_baseline"] = multi_rank_cpu_baseline(hosts, m["gathered"], B, m["tm"], m["tfr"], m["eng_cfg"], n0,
-                                                           results_from_torch(m["out"]["results"][:n0]))
+                                                           results_from_torch(m["out"]["results"][:n0]), kind=m["exchange_kind"],
+                                                           own_scores=m["out"]["scores"][:n0])
+            line["workload_stats"] = workload_stats(hosts[0][:WORKLOAD_STATS_N], m["eng_cfg"], args.gain)
         if world == 1 and not args.no_cpu_baseline:
+            line["workload_stats"] = workload_stats(synth.as_u16_numpy(m["pcm"][:WORKLOAD_STATS_N]), m["eng_cfg"], args.gain)
             line["cpu_baseline"] = cpu_baseline(m["pcm"], m["eng"], m["out"], m["tm"], m["tfr"], args.cpu_sample, m["eng_cfg"],
                                                 one_thread_n=64)
             if args.workload == "ref":
@@ -729,6 +768,8 @@ def run_rank(args):
             sc = args.other_scale
             line["other_configs"] = [other_config("ref", 4096 // sc, 10, args.other_steps, local_rank, cpu_n),
                                      other_config("ext", 65536 // sc, 500, args.other_steps, local_rank, cpu_n and 128)]
+            if args.gain == 1.0:  # the metric's configuration once more, at the amplitudes SURVEY.md 8(d) specifies (200-600)
+                line["other_configs"].insert(0, other_config("ref", 65536 // sc, 100, args.other_steps, local_rank, cpu_n, gain=SURVEY_GAIN))
             # the scorer BASELINE.json's north_star describes (anti-diagonal wavefront), opt-in and non-reference: timed alone
             line["other_configs"].append(measure_dp(65536 // sc, K_DEFAULT, min(3, args.other_steps), 0, local_rank,
                                                     parity_n=64 if cpu_n else 0))
@@ -740,19 +781,27 @@ def run_rank(args):
     return 0
 
 
+_PMC_PATH = ("k_vad.hip", "sr_vad_dev.h", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h", "sr_tables.h")
 PMC_SOURCES = {  # the translation units (+ the device headers they include) each committed PMC file depends on
-    "pmc_traffic.json": ("k_mfcc.hip", "sr_dev.h", "sr_fft_dev.h", "sr_device.h"),
-    "pmc_valu.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
-    "pmc_valu_dp.json": ("k_dtw_dp.hip", "sr_dev.h", "sr_dtw_dev.h", "sr_device.h"),
-    "pmc_valu_k10.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
-    "pmc_valu_ext.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc_ext.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h"),
+    # (sr_tables.h holds the tier bounds and fused multipliers that steer k_mfcc's instruction mix)
+    "pmc_traffic.json": ("k_mfcc.hip", "sr_dev.h", "sr_fft_dev.h", "sr_device.h", "sr_tables.h"),
+    "pmc_valu.json": _PMC_PATH,
+    "pmc_valu_loud.json": _PMC_PATH,
+    "pmc_valu_dp.json": ("k_dtw_dp.hip", "sr_dev.h", "sr_dtw_dev.h", "sr_device.h", "sr_tables.h"),
+    "pmc_valu_k10.json": _PMC_PATH,
+    "pmc_valu_ext.json": ("k_vad.hip", "sr_vad_dev.h", "k_mfcc_ext.hip", "k_dtw.hip", "sr_dev.h", "sr_fft_dev.h", "sr_dtw_dev.h", "sr_device.h",
+                          "sr_tables.h"),
 }
 
 
-def valu_pmc_file(workload, B, Kt):
-    """the committed PMC file (issue slots per utterance) that belongs to a workload shape, or None"""
+def valu_pmc_file(workload, B, Kt, gain=1.0):
+    """the committed PMC file (issue slots per utterance) that belongs to a workload shape and amplitude, or None"""
     if workload == "ext":
-        return "pmc_valu_ext.json" if Kt == 500 else None
+        return "pmc_valu_ext.json" if (Kt == 500 and gain == 1.0) else None
+    if gain == SURVEY_GAIN:
+        return "pmc_valu_loud.json" if Kt == 100 else None
+    if gain != 1.0:
+        return None
     return "pmc_valu.json" if Kt == 100 else "pmc_valu_k10.json" if Kt == 10 else None
 
 
@@ -779,6 +828,10 @@ def valu_roofline(which, B, step_ms, sclk):
                 "cycles_per_slot": 4.0, "clock_hz_assumed": 2.4e9,
                 "clock_hz_measured": sclk["mean_mhz"] * 1e6 if sclk else None,
                 "frac_at_measured_clock": achv / (1024 * sclk["mean_mhz"] * 1e6 / 4.0) if sclk else None,
+                # the SECOND denominator: MI355X_MICROARCH.md's datasheet rate of one wave64 VALU instruction per SIMD per 2
+                # cycles (reached only by a pure run of full-rate ops, profiles/r02/VALU_ISSUE.md) -- instructions, not slots
+                "frac_vs_2cycle_peak": insts * B / (step_ms * 1e-3) / (1024 * 2.4e9 / 2.0),
+                "peak_2cycle": 1024 * 2.4e9 / 2.0,
                 "source": vj.get("source"), "pmc_file": "profiles/" + which,
                 "rates_source": "profiles/r02/VALU_ISSUE.md (per-opcode s_memtime micro-benchmark)",
                 "note": "derived: slot counts from the committed PMC pass x this run's step time; the chip "
@@ -831,10 +884,12 @@ def headline(args, m, world, backend="nccl", launcher=None):
             traffic_src = tj.get("source")
         except Exception:
             traffic = traffic_iso = None
-    roofline_valu, valu_stale = valu_roofline(valu_pmc_file(args.workload, B, Kt), B, stage["total"], m.get("sclk"))
+    gain = m.get("gain", 1.0)
+    roofline_valu, valu_stale = valu_roofline(valu_pmc_file(args.workload, B, Kt, gain), B, stage["total"], m.get("sclk"))
     par = f"utterance-sharded x{world}"
     if world > 1:
-        par += ", RCCL all-gather of scores" if backend == "nccl" else f", all-gather of scores over {backend} (TEST HOOK, not RCCL)"
+        what = "scores" if m.get("exchange_kind", "scores") == "scores" else "result records (--exchange results)"
+        par += f", RCCL all-gather of {what}" if backend == "nccl" else f", all-gather of {what} over {backend} (TEST HOOK, not RCCL)"
     line = {
         "metric": f"utterances/sec (256-frame, {Kt} templates)" if args.workload == "ref"
         else f"utterances/sec (EXTENSION: 16 kHz/512-pt/40 Mel, 256-frame, {Kt} templates; no reference counterpart)",
@@ -850,9 +905,10 @@ def headline(args, m, world, backend="nccl", launcher=None):
         "dtype": "int32",
         "data": "synthetic",
         "exchange": m.get("exchange"),
-        "config": {"workload": workload_name(args.workload, B, Kt) + (f" (strong scaling: global batch {args.batch_global})"
-                                                                       if getattr(args, "batch_global", None) else ""),
-                   "batch_per_gpu": B, "templates": Kt, "frames": T, "buf_len": S, "parallelism": par},
+        "config": {"workload": workload_name(args.workload, B, Kt, gain) + (f" (strong scaling: global batch {args.batch_global})"
+                                                                             if getattr(args, "batch_global", None) else ""),
+                   "batch_per_gpu": B, "templates": Kt, "frames": T, "buf_len": S, "parallelism": par, "gain": gain},
+        "workload_stats": None,  # filled by the CPU legs (see workload_stats)
         # HBM roofline of the dominant kernel, as the contract defines it: algorithmic bytes of one launch / the duration
         # of that launch.  achieved / frac = the kernel ALONE on the chip, one launch over the whole batch (hipEvents on
         # its stream, in the pass right after the timed steps) -- the figure profiles/*_rocprof_summary.csv reproduces.
@@ -875,6 +931,7 @@ def headline(args, m, world, backend="nccl", launcher=None):
                      "timed_step_note": "SURVEY 8(d)'s whole-path algorithmic bytes per utterance x B / ms_per_step / 8 TB/s",
                      "valu_frac": roofline_valu["frac"] if roofline_valu else None,
                      "valu_frac_at_measured_clock": roofline_valu["frac_at_measured_clock"] if roofline_valu else None,
+                     "valu_frac_vs_2cycle_peak": roofline_valu["frac_vs_2cycle_peak"] if roofline_valu else None,
                      "valu_note": "the BINDING ceiling: 4-cycle VALU issue slots of a timed step / (1024 SIMDs x clock / 4), "
                                   "details under roofline_valu; null when the committed PMC file is stale or absent for this shape",
                      "note": "the path is integer-VALU-issue-bound, not HBM-bound (DESIGN.md 3.2): see roofline_valu"},
@@ -1012,7 +1069,7 @@ def cpu_baseline(pcm, eng, out, tm, tfr, n, eng_cfg, one_thread_n=0):
 PER_RANK_PARITY_N = 128  # N > 1: utterances of EVERY rank's shard that are checked against the CPU reference
 
 
-def multi_rank_cpu_baseline(host_per_rank, gathered, B, tm, tfr, eng_cfg, n0, own_results=None):
+def multi_rank_cpu_baseline(host_per_rank, gathered, B, tm, tfr, eng_cfg, n0, own_results=None, kind="scores", own_scores=None):
     """N > 1 (rank 0 / the single process): `cpu_baseline` + a parity flag that covers every rank's shard.  The sample is the
     first n0 utterances of rank 0's shard followed by the first len(host_per_rank[r]) utterances of every other rank's
     shard; the GPU side of the comparison is read from the GATHERED score matrix (what the exchange step delivered:
@@ -1029,20 +1086,30 @@ def multi_rank_cpu_baseline(host_per_rank, gathered, B, tm, tfr, eng_cfg, n0, ow
     rows = np.concatenate(rows)
     host = np.concatenate(hosts)
     g = gathered[torch.from_numpy(rows).to(gathered.device)]
-    best, mn = du.argmin_first(g)
-    gsc = g.cpu().numpy().view(np.uint32)
-    gbest, gdis = best.cpu().numpy().astype(np.uint32), mn.cpu().numpy().astype(np.uint32)
+    if kind == "results":
+        # --exchange results: the gathered rows ARE the kernels' result records (argmin and distance of every rank's utterances);
+        # the score matrix stays on its rank, so scores are compared for rank 0's rows only (cpu_baseline_arrays: first len(gsc) rows)
+        rec = results_from_torch(g)
+        gbest, gdis = rec["best_tpl"].astype(np.uint32), rec["min_dis"].astype(np.uint32)
+        gsc = own_scores[:len(hosts[0])].cpu().numpy().view(np.uint32)
+    else:
+        best, mn = du.argmin_first(g)
+        gsc = g.cpu().numpy().view(np.uint32)
+        gbest, gdis = best.cpu().numpy().astype(np.uint32), mn.cpu().numpy().astype(np.uint32)
     own_ok = None
     if own_results is not None:  # rank 0's kernels' own records against the scan of the gathered rows
         k = min(len(own_results), len(rows), n0)
         own_ok = bool(np.array_equal(own_results["best_tpl"][:k], gbest[:k]) and np.array_equal(own_results["min_dis"][:k], gdis[:k]))
     cb = cpu_baseline_arrays(host, gsc, gbest, gdis, tm, tfr, eng_cfg,
                              f"first {len(hosts[0])} utterances of rank 0's shard + first {PER_RANK_PARITY_N} of each of the other "
-                             f"{world - 1} ranks' shards ({len(rows)} utterances; GPU scores taken from the gathered matrix)",
+                             f"{world - 1} ranks' shards ({len(rows)} utterances; GPU " +
+                             ("scores taken from the gathered matrix)" if kind == "scores" else
+                              "argmin / distance taken from the gathered result records, scores from rank 0's own matrix)"),
                              one_thread_n=32)
     cb["per_rank_sample"] = {"ranks": world, "utterances_per_rank": [int(len(h)) for h in hosts],
-                             "gpu_side": "rows r*B .. of the all-gathered score matrix on rank 0; argmin / min_dis re-derived by the "
-                                         "strict-< slot scan (main.c:279-291)",
+                             "gpu_side": ("rows r*B .. of the all-gathered score matrix on rank 0; argmin / min_dis re-derived by the "
+                                          "strict-< slot scan (main.c:279-291)") if kind == "scores" else
+                                         "rows r*B .. of the all-gathered result records on rank 0",
                              "rank0_result_records_agree_with_gathered_scan": own_ok}
     if own_ok is False:
         cb["gpu_results_identical_on_sample"] = False
@@ -1075,7 +1142,8 @@ def cpu_baseline_arrays(host, gsc, gbest, gdis, tm, tfr, eng_cfg, what, one_thre
     t0 = time.perf_counter()
     ores, _, osc = orc.recognize_batch(host, tpl, n_threads=cores, want_mfcc=False, want_scores=True)
     dt_port = time.perf_counter() - t0
-    match_port = bool(np.array_equal(gsc, osc) and np.array_equal(gres["best_tpl"], ores["best_tpl"]))
+    ns = len(gsc)  # scores may cover only the leading rows (--exchange results: the other ranks' matrices are not gathered)
+    match_port = bool(np.array_equal(gsc, osc[:ns]) and np.array_equal(gres["best_tpl"], ores["best_tpl"]))
     port = {"value": n / dt_port, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": where + ", gcc -O2 oracle (tier ii)", "seconds": dt_port,
             "gpu_results_identical_on_sample": match_port}
@@ -1100,7 +1168,7 @@ def cpu_baseline_arrays(host, gsc, gbest, gdis, tm, tfr, eng_cfg, what, one_thre
         r1 = pool.recognize(host, store, Kt, stride, n_run=n1, threads=1)
         cores_1 = {"value": n1 / r1["seconds"], "unit": "utterances/s", "cores": 1, "utterances": n1}
     pool.close()
-    match = bool((r_st == 0).all() and np.array_equal(gsc, r_sc) and np.array_equal(gres["best_tpl"], r_best)
+    match = bool((r_st == 0).all() and np.array_equal(gsc, r_sc[:ns]) and np.array_equal(gres["best_tpl"], r_best)
                  and np.array_equal(gres["min_dis"], r_dis))
     return {"value": n / dt, "unit": "utterances/s", "cores": cores, "kind": "reference",
             "sample": where + ", the reference's own VAD.C/MFCC.C/DTW.C objects (gcc -O2, vv_tim_max raised to 320 frames) "

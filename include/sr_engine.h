@@ -129,6 +129,12 @@ int sr_build_tie_table(int8_t *out);
  * still succeeds, sr_last_error() holds a warning, and this returns the number of differing entries of the last
  * sr_create / sr_build_tables of the process (0 = this host agrees). */
 int sr_log_table_mismatches(void);
+/* The magnitude stage of the reference front end's frame kernel, (u32)(sqrtf(re^2+im^2)*10) (MFCC.C:56-58), takes the
+ * uncorrected v_sqrt_f32 on frames whose largest re^2+im^2 is at most 70 171: equal to the exact form there on gfx950, a
+ * property of the chip that sr_create re-checks on the device it runs on by sweeping the whole range.  Returns the bound
+ * in use for this engine: 70171 after a clean sweep, 0 (every frame takes the exactly corrected root; sr_last_error()
+ * holds a warning from sr_create) otherwise, and for front ends whose kernels do not use the form. */
+uint32_t sr_mag_cheap_bound(const sr_engine *h);
 
 /* ------------------------------------------------------------------ template store
  * The firmware keeps templates as v_ftr_tag images in MCU flash at a 4 KiB stride
@@ -240,6 +246,12 @@ int sr_delta_mfcc_batch_dev(sr_engine *h, const int16_t *d_mfcc, const sr_vad_re
                             uint32_t B, int16_t *d_delta, void *stream);
 /* generic 1024-point Q15 FFT of n independent packed-complex arrays (re = low half, im = high half) */
 int sr_fft_q15_batch(sr_engine *h, const uint32_t *in, uint32_t *out, uint32_t n);
+/* batched forms of the two small scalar symbols below (the same kernels get_dis() / dtw_limit() launch with n = 1):
+ * get_dis (DTW.C:45-62) on n pairs of 12-coefficient rows a[i*12..], b[i*12..];
+ * dtw_limit (DTW.C:76-109) on n points xy[2i] = x, xy[2i+1] = y for the file statics a dtw() call of in_frames against
+ * mdl_frames leaves behind (DTW.C:129-130, 141-142); out[i] = 1: the point lies outside the parallelogram. */
+int sr_get_dis_batch(sr_engine *h, const int16_t *a, const int16_t *b, uint32_t n, uint32_t *out);
+int sr_dtw_limit_batch(sr_engine *h, const uint16_t *xy, uint32_t n, uint32_t in_frames, uint32_t mdl_frames, uint8_t *out);
 
 /* ------------------------------------------------------------------ multi-GPU (one process, several MI355X)
  * Utterances are sharded over the devices (B_per_dev each), templates are replicated, the argmin is local, and the
@@ -319,6 +331,7 @@ int sr_get_stage_launches(sr_engine *h, uint32_t *launches_per_call);
  *   "mfcc_grid"                      workgroups of the frame kernel (read by sr_create)
  *   "dtw_debug"                      print the DTW geometry when a store is set
  *   "perturb_log_thr", "log_thr_from_host"   exercise / bypass the shipped log-step-table check (sr_log_table_mismatches)
+ *   "mag_cheap_off"                  sr_create behaves as if its device sweep of the cheap magnitude form had failed
  *   "multi_allow_dup"                sr_multi_create accepts one device several times; honoured only when SR_RCCL_LIBRARY
  *                                    names the collective library explicitly (1-GPU tests over the in-process RCCL double)
  * Unknown names return SR_ERR_BAD_ARG. */
@@ -346,6 +359,11 @@ int sr_mel_term_sweep(sr_engine *h, uint32_t tri_lo, uint32_t tri_hi, uint32_t e
  * With bit 31 of n_max set the sweep compares what the DTW kernel's small-root form uses, floor(v_sqrt_f32((float)d)), with the
  * exact (u32)sqrtf((float)d) of DTW.C:59 for every d in [0, n_max & 0x7fffffff]. */
 int sr_mag_fast_sweep(sr_engine *h, uint32_t n_max, uint64_t out[2]);
+/* diagnostics: fill the whole local data share of every compute unit with a seeded pattern (asynchronous on `stream`; one
+ * workgroup per CU at a time, each taking the device's full per-CU LDS).  *bytes_per_cu (optional) receives the bytes
+ * each workgroup filled (163840 on MI355X).  The test suite launches it between calls: a kernel that reads LDS it has not
+ * written itself gets the same values only as long as the CU's previous tenant was a workgroup of the same kernel. */
+int sr_lds_poison(sr_engine *h, uint32_t seed, void *stream, uint32_t *bytes_per_cu);
 /* diagnostics: per-utterance ballots of the VAD "loud" decision (VAD.C:164), 63 frames per 64-bit word, 16 words */
 int sr_vad_debug_masks(sr_engine *h, const uint16_t *pcm, uint64_t pcm_stride, uint32_t buf_len, uint32_t B,
                        sr_vad_rec *vad, uint64_t *masks);

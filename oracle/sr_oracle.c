@@ -345,6 +345,36 @@ uint32_t sr_oracle_mfcc(const sr_oracle *o, const uint16_t *buf, int32_t start, 
     return cnt;
 }
 
+/* Diagnostic (describes an input, computes nothing of the path): the largest re^2 + im^2 (MFCC.C:56-57) over the first
+   nfft/2 bins of every frame of the segment [start, end), frames windowed as in MFCC.C:115-124.  bench.py reports from it
+   which magnitude / filterbank tier of the device's frame kernel a workload's frames fall into.  Returns the frame count. */
+uint32_t sr_oracle_frame_peaks(const sr_oracle *o, const uint16_t *buf, int32_t start, int32_t end,
+                               const sr_oracle_atap *atap, uint32_t *peaks, uint32_t max_out)
+{
+    uint32_t fl = o->frame_len, hop = o->hop, cnt = 0;
+    int32_t mid = (int32_t)atap->mid_val;
+    for (int32_t p = start; p <= end - (int32_t)fl && cnt < max_out; p += (int32_t)hop) {
+        uint32_t in[1024], out[1024], mx = 0;
+        const uint16_t *x = buf + p;
+        for (uint32_t i = 0; i < fl; i++) {
+            int32_t t = ((int32_t)x[i] - mid) - ((int32_t)x[(int32_t)i - 1] - mid) * 95 / 100;
+            in[i] = (uint16_t)(int16_t)(t * (int32_t)o->hamm[i] / (10000 / 10));
+        }
+        for (uint32_t i = fl; i < o->cfg.nfft; i++) in[i] = 0;
+        if (o->cfg.nfft == 1024)
+            cr4_fft_1024_stm32(out, in, 1024);
+        else
+            sr_oracle_q15_fft512(out, in);
+        for (uint32_t i = 0; i < o->frq_max; i++) {
+            int32_t re = (int16_t)out[i], im = (int16_t)(out[i] >> 16);
+            uint32_t r = (uint32_t)(re * re + im * im);
+            if (r > mx) mx = r;
+        }
+        peaks[cnt++] = mx;
+    }
+    return cnt;
+}
+
 /* ---- DTW.C:45-62 -------------------------------------------------------- */
 uint32_t sr_oracle_get_dis(const int16_t *a, const int16_t *b, uint32_t n_coef)
 {

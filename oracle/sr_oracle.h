@@ -81,6 +81,9 @@ int sr_oracle_fft_mag(const sr_oracle *o, const int16_t *frame, uint32_t len, ui
 /* MFCC.C:86-191.  buf[start-1] is read (MFCC.C:119).  Returns frm_num (0 if > max_frames). */
 uint32_t sr_oracle_mfcc(const sr_oracle *o, const uint16_t *buf, int32_t start, int32_t end,
                         const sr_oracle_atap *atap, int16_t *mfcc);
+/* diagnostic: largest re^2 + im^2 (MFCC.C:56-57) of each frame of the segment; returns the number of frames written */
+uint32_t sr_oracle_frame_peaks(const sr_oracle *o, const uint16_t *buf, int32_t start, int32_t end,
+                               const sr_oracle_atap *atap, uint32_t *peaks, uint32_t max_out);
 /* DTW.C:45-62 */
 uint32_t sr_oracle_get_dis(const int16_t *a, const int16_t *b, uint32_t n_coef);
 /* DTW.C:120-192.  Frames past *_frames may be read (do-while), exactly as the reference does. */

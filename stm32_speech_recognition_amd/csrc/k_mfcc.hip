@@ -3,6 +3,10 @@
 // Every kernel reproduces the reference's integer arithmetic bit for bit; cited lines are relative to the reference tree.
 #include "sr_fft_dev.h"
 
+#ifndef SR_MEL_CHUNKED
+#define SR_MEL_CHUNKED 1  // experiment switch (profiles/experiments/RESULTS.md, round 6): 0 = bin-major scratch order of round 5
+#endif
+
 namespace sr {
 
 // ------------------------------------------------------------------------------------------------
@@ -59,6 +63,10 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     // (sr_tables.h mel_fused_multiplier), parked in LDS as lane-contiguous 16-byte chunks like the pass-5 coefficients
     // (chunk c of lane l at s_tm[64 c + l]: even 0-3, even 4-7, odd 0-3, odd 4-7; conflict-free ds_read_b128, and LDS
     // instructions do not take VALU issue slots): held in 16 VGPRs for the whole kernel they pushed it past 128
+    // (-DSR_INJECT_LDS_RACE=1 / =2, fault injection for the suite's race-class tests -- profiles/experiments/ab_build.sh race2 . -DSR_INJECT_LDS_RACE=2:
+    // the fill is moved BEHIND the barrier, which is the defect round 5's soak found; level 2 also delays the late writer, which
+    // opens the window on every workgroup instead of once in thousands of calls; what the tests make of both: RESULTS.md, round 6)
+#ifndef SR_INJECT_LDS_RACE
     if (w == 2 % kMfccWaves) {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -66,17 +74,51 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             s_tm[64 * (c + 2) + lane] = *(const u32x4 *)(a.t.tri_odd_m + 8 * lane + 4 * c);
         }
     }
+#endif
     __syncthreads();  // every table above is written by ONE wave and read by all of them: nothing shared is written below this line
+#ifdef SR_INJECT_LDS_RACE
+    if (w == 2 % kMfccWaves) {
+#if SR_INJECT_LDS_RACE >= 2  // level 2: the late writer is also held back ~3.4 us (what a slow table load does to it once in thousands of calls)
+        __builtin_amdgcn_s_sleep(127);
+#endif
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            s_tm[64 * c + lane] = *(const u32x4 *)(a.t.tri_even_m + 8 * lane + 4 * c);
+            s_tm[64 * (c + 2) + lane] = *(const u32x4 *)(a.t.tri_odd_m + 8 * lane + 4 * c);
+        }
+    }
+#endif
     int hamm_m[3];  // window weights of the lane's three samples as fused multipliers (sr_tables.h hamm_fused_multiplier)
 #pragma unroll
     for (int k = 0; k < 3; k++) hamm_m[k] = (lane + 64 * k < kFrameLen) ? hamm_fused_multiplier(a.t.hamm[lane + 64 * k]) : 0;
     // filter h < 24 owned by lane h: bins [lo, hi) of poly-line (h & 1)  (MFCC.C:136-162)
-    int f_lo = 0, f_hi = 0;
+    // prefix P[j] of bin j = 8 l + k sits at word 256 (k >> 2) + 4 l + (k & 3) of its poly-line's half (chunked order, see the
+    // magnitude stage), the lane offsets X[l] behind them: the addresses of P[hi - 1] / P[lo - 1] are lane constants
+    int f_lo = 0, p_hi = 0, p_lo = 0, x_hi = 0, x_lo = 0;
     if (lane < kMel) {
         const int h = lane;
         f_lo = (h == 0) ? 0 : (int)a.t.tri_cen[h - 1];
-        f_hi = (h == kMel - 1) ? kBins : (int)a.t.tri_cen[h + 1];
+        const int f_hi = (h == kMel - 1) ? kBins : (int)a.t.tri_cen[h + 1];
+        const int ih = f_hi - 1, il = f_lo ? f_lo - 1 : 0, half = (h & 1) ? kBins : 0;
+#if SR_MEL_CHUNKED
+        p_hi = half + 256 * ((ih >> 2) & 1) + 4 * (ih >> 3) + (ih & 3), x_hi = ih >> 3;
+        p_lo = half + 256 * ((il >> 2) & 1) + 4 * (il >> 3) + (il & 3), x_lo = il >> 3;
+#else
+        p_hi = half + ih, x_hi = ih >> 3;
+        p_lo = half + il, x_lo = il >> 3;
+#endif
     }
+    const uint32_t tw_off = 32u * (uint32_t)lane;  // byte offset of the lane's eight raw filterbank weights (LOUD / MID tiers)
+    // bin lane + 64 e3 (+ 256) of the magnitude stage in the same order: word e_base + 32 e3 (+ 128)
+#if SR_MEL_CHUNKED
+    const int e_base = 256 * ((lane >> 2) & 1) + 4 * (lane >> 3) + (lane & 3);
+    constexpr int kEs = 32, kEh = 128;
+    const int c0 = 4 * lane, c1 = 256 + 4 * lane;
+#else
+    const int e_base = lane;
+    constexpr int kEs = 64, kEh = 256;
+    const int c0 = 8 * lane, c1 = 8 * lane + 4;
+#endif
 
     // the per-utterance record of the NEXT work item is fetched while the current one is processed
     uint32_t item = blockIdx.x;
@@ -152,21 +194,46 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 nn[2 * e3] = (uint32_t)sdot2z(u[e3][0], u[e3][0]);
                 nn[2 * e3 + 1] = (uint32_t)sdot2z(u[e3][1], u[e3][1]);
             }
-            // ---- |X|*10 and energy (MFCC.C:49-60, 128-133).  A QUIET frame -- every re^2 + im^2 of the frame <= kMagSmallMax, i.e.
-            // |X|*10 <= 1638 and E <= kMelFusedMaxE; decided for the whole wave, so the branch is uniform; 97.8 % of the benchmark's
-            // frames -- takes (u32)(v_sqrt_f32 * 10) for the magnitude (exact for every n <= 70 171 on gfx950, swept on the device
-            // by sr_mag_fast_sweep; 6.5 issue slots per bin) and the fused filterbank term below; any other frame the exactly
-            // corrected root (8.5 slots per bin; all 2^32 inputs certified, sr_dev.h sqrt_rn_int) and the literal filterbank form.
+            // ---- |X|*10 and energy (MFCC.C:49-60, 128-133), three tiers by the largest re^2 + im^2 of the frame, decided for the whole
+            // wave so that every branch is uniform:
+            //   QUIET  (<= kMagSmallMax = 26 843, i.e. |X|*10 <= 1638 and E <= kMelFusedMaxE): cheap magnitude + fused filterbank term
+            //   MID    (<= a.mag_cheap_max = 70 171 on gfx950, |X|*10 <= 2648):              cheap magnitude + literal filterbank term
+            //   LOUD   (anything else):                                                     exact magnitude + literal filterbank term
+            // cheap magnitude = (u32)(v_sqrt_f32 * 10): equal to the exact form for every n <= 70 171 on gfx950 -- a property of this
+            // chip's v_sqrt_f32, so sr_create sweeps the whole range on the device it runs on and passes 0 if it does not hold
+            // (sr_engine.cpp, sr_mag_fast_sweep); 4.5 issue slots per bin against 6.5 for the exactly corrected root (all 2^32 inputs
+            // certified, sr_dev.h sqrt_rn_int).  At the benchmark's amplitudes 97-99 % of the frames are QUIET; at SURVEY 8(d)'s
+            // (gain 2.4) 29 % QUIET / 47 % MID / 24 % LOUD; near-clipping captures are LOUD (profiles/experiments/RESULTS.md).
             const uint32_t nmax = max(max(max(max(nn[0], nn[1]), nn[2]), max(max(nn[3], nn[4]), nn[5])), max(nn[6], nn[7]));
             const bool quiet = __builtin_expect(__builtin_amdgcn_ballot_w64(nmax > kMagSmallMax) == 0, 1);
-            if (quiet) {
+            // the literal filterbank form multiplies by the weights themselves: requested from the (cache-resident) table now, they
+            // arrive behind the magnitude stage.  Kept out of LDS (the workgroup's share is full at four workgroups per CU) and out
+            // of the quiet path's registers.
+            u32x4 tw_e[2], tw_o[2];
+            bool cheap = true;
+            if (!quiet) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    tw_e[c] = *(const u32x4 *)((const char *)a.t.tri_even32 + tw_off + 16 * c);
+                    tw_o[c] = *(const u32x4 *)((const char *)a.t.tri_odd32 + tw_off + 16 * c);
+                }
+                cheap = __builtin_amdgcn_ballot_w64(nmax > a.mag_cheap_max) == 0;
+            } else {
+                // never read on this path: "defined" by an empty asm so that the quiet frame does not pay 16 register clears
+                asm volatile("" : "=v"(tw_e[0]), "=v"(tw_e[1]), "=v"(tw_o[0]), "=v"(tw_o[1]));
+            }
+            // energies go to the wave's scratch in the CHUNKED order the filterbank reads them in: bin 8 l + k at word
+            // 256 (k >> 2) + 4 l + (k & 3), so that lane l's two 16-byte reads (and the prefix stores below) are lane-contiguous
+            // 16-byte chunks -- conflict-free; 8-word lane strides put two lanes of every service group on the same banks
+            uint32_t *eb = buf + e_base;
+            if (cheap) {
 #pragma unroll
                 for (int e3 = 0; e3 < 4; e3++) {
                     const f32x2 m = f32x2{__builtin_amdgcn_sqrtf((float)(int)nn[2 * e3]), __builtin_amdgcn_sqrtf((float)(int)nn[2 * e3 + 1])} *
                                     f32x2{10.0f, 10.0f};
                     const uint32_t m0 = cvt_u32(m.x), m1 = cvt_u32(m.y);
-                    buf[lane + 64 * e3] = umul24(m0, m0);
-                    buf[lane + 64 * e3 + 256] = umul24(m1, m1);
+                    eb[kEs * e3] = umul24(m0, m0);
+                    eb[kEs * e3 + kEh] = umul24(m1, m1);
                 }
             } else {
 #pragma unroll
@@ -174,21 +241,20 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                     // both bins' roots and the x10 in packed f32 operations (plain IEEE multiplies and fused multiply-adds, see sqrt_rn_int)
                     const f32x2 m = sqrt_rn_int2(f32x2{(float)(int)nn[2 * e3], (float)(int)nn[2 * e3 + 1]}) * f32x2{10.0f, 10.0f};
                     const uint32_t m0 = cvt_u32(m.x), m1 = cvt_u32(m.y);  // < 2^19
-                    buf[lane + 64 * e3] = umul24(m0, m0);
-                    buf[lane + 64 * e3 + 256] = umul24(m1, m1);
+                    eb[kEs * e3] = umul24(m0, m0);
+                    eb[kEs * e3 + kEh] = umul24(m1, m1);
                 }
             }
             wave_sync();
             // ---- Mel filterbank as prefix sums over bins (each term /100 before summing, u32 wrap)
             uint32_t pe[8], po[8], xe, xo;
             {
-                const uint4 q0 = *(const uint4 *)(buf + 8 * lane), q1 = *(const uint4 *)(buf + 8 * lane + 4);
+                const uint4 q0 = *(const uint4 *)(buf + c0), q1 = *(const uint4 *)(buf + c1);
                 const uint32_t e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
                 uint32_t se = 0, so = 0;
                 // E*tri/100 (MFCC.C:139-161): in a quiet frame (every E <= kMelFusedMaxE, see above) a term is ONE v_mul_hi_u32 of
                 // E << 4 with the per-bin multiplier (the shift shared by both poly-lines): 5 instructions per bin instead of 8
-                // (mul_lo, mul_hi, shift, add per term).  A louder frame takes the literal u32-wrapping form with tri recovered
-                // from the multiplier.
+                // (mul_lo, mul_hi, shift, add per term).  A louder frame takes the literal u32-wrapping form.
                 if (quiet) {
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
@@ -205,11 +271,10 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 } else {
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
-                        const u32x4 me = s_tm[64 * c + lane], mo = s_tm[64 * (c + 2) + lane];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            se += e[4 * c + k] * mel_tri_of_multiplier(me[k]) / 100u;
-                            so += e[4 * c + k] * mel_tri_of_multiplier(mo[k]) / 100u;
+                            se += e[4 * c + k] * tw_e[c][k] / 100u;
+                            so += e[4 * c + k] * tw_o[c][k] / 100u;
                             pe[4 * c + k] = se;
                             po[4 * c + k] = so;
                         }
@@ -222,17 +287,16 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
             // store below goes to words nobody reads before the next wave_sync)
             // in-lane prefixes and the per-lane offsets are stored separately: the 24 filter lanes add them on lookup
             // (2 adds) instead of every lane adding its offset to 16 prefixes
-            *(uint4 *)(buf + 8 * lane) = make_uint4(pe[0], pe[1], pe[2], pe[3]);
-            *(uint4 *)(buf + 8 * lane + 4) = make_uint4(pe[4], pe[5], pe[6], pe[7]);
-            *(uint4 *)(buf + kBins + 8 * lane) = make_uint4(po[0], po[1], po[2], po[3]);
-            *(uint4 *)(buf + kBins + 8 * lane + 4) = make_uint4(po[4], po[5], po[6], po[7]);
+            *(uint4 *)(buf + c0) = make_uint4(pe[0], pe[1], pe[2], pe[3]);
+            *(uint4 *)(buf + c1) = make_uint4(pe[4], pe[5], pe[6], pe[7]);
+            *(uint4 *)(buf + kBins + c0) = make_uint4(po[0], po[1], po[2], po[3]);
+            *(uint4 *)(buf + kBins + c1) = make_uint4(po[4], po[5], po[6], po[7]);
             buf[2 * kBins + lane] = xe;
             moff[lane] = xo;
             wave_sync();
             if (lane < kMel) {
-                const uint32_t *P = buf + ((lane & 1) ? kBins : 0), *X = (lane & 1) ? moff : buf + 2 * kBins;
-                const int ih = f_hi - 1, il = f_lo - 1;
-                const uint32_t hi = P[ih] + X[ih >> 3], lo = f_lo ? P[il] + X[il >> 3] : 0u;
+                const uint32_t *X = (lane & 1) ? moff : buf + 2 * kBins;
+                const uint32_t hi = buf[p_hi] + X[x_hi], lo = f_lo ? buf[p_lo] + X[x_lo] : 0u;
                 powb[fi * kMelPad + lane] = hi - lo;
             }
             wave_sync();

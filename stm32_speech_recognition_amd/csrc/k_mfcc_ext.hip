@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
             s_w512[c * 16 + gl] = u32x4{a.t.w512_a[k0], a.t.w512_b[k0], a.t.w512_a[k1], a.t.w512_b[k1]};
         }
     }
+#ifndef SR_INJECT_LDS_RACE  // (fault injection for the suite's race-class tests, see k_mfcc.hip: the fill moves behind the barrier)
     if (w == 2 % kWaves && lane < 16) {  // triangle weights of the bins 16*gl .. 16*gl + 15 (filterbank layout)
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
             s_tri[c * 16 + gl] = u32x4{a.t.tri_even[b0], a.t.tri_odd[b0], a.t.tri_even[b0 + 1], a.t.tri_odd[b0 + 1]};
         }
     }
+#endif
     // filters h = gl, gl + 16, gl + 32 (< 40) of the lane's frame: bins [lo, hi) of poly-line h & 1 (MFCC.C:136-162)
     uint32_t f_lohi[3];  // f_lo << 16 | f_hi (both <= 256)
 #pragma unroll
@@ -116,6 +118,18 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
         f_lohi[q] = ((uint32_t)lo << 16) | (uint32_t)hi;
     }
     __syncthreads();
+#ifdef SR_INJECT_LDS_RACE
+    if (w == 2 % kWaves && lane < 16) {
+#if SR_INJECT_LDS_RACE >= 2  // level 2: the late writer is also held back ~3.4 us (what a slow table load does to it once in thousands of calls)
+        __builtin_amdgcn_s_sleep(127);
+#endif
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int b0 = 16 * gl + 2 * c;
+            s_tri[c * 16 + gl] = u32x4{a.t.tri_even[b0], a.t.tri_odd[b0], a.t.tri_even[b0 + 1], a.t.tri_odd[b0 + 1]};
+        }
+    }
+#endif
 
     // Work items are (utterance, tile of kTile frames); the records of the next two items are read ahead, and the
     // samples of the NEXT batch of four frames (same item, or the first batch of the next item that has frames) are

@@ -170,4 +170,37 @@ void launch_dtw_limit(const uint16_t *xy, uint8_t *out, uint32_t n, int X1, int 
     hipLaunchKernelGGL(k_dtw_limit, dim3((n + 63) / 64), dim3(64), 0, s, xy, out, n, X1, X2, in_n, mdl_n);
 }
 
+// ------------------------------------------------------------------------------------------------
+// diagnostics: fill the WHOLE local data share of every compute unit with a seeded pattern (tests: a kernel that reads LDS it
+// has not written -- a table filled behind the last barrier, a region sized one row short -- computes the same values as
+// long as the previous tenant of the CU was a workgroup of the same kernel; after this launch it cannot).  One workgroup
+// takes all of a CU's LDS (dynamic size = the device's per-workgroup maximum), so at most one is resident per CU; each
+// writes its whole allocation and then waits ~20 us so that the dispatcher has to spread the grid over every CU.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lds_poison(uint32_t seed, uint32_t words, uint32_t spin)
+{
+    extern __shared__ uint32_t poison[];
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) poison[i] = (seed ^ (i * 2654435761u)) | 0x80000000u;
+    __syncthreads();
+    uint32_t acc = 0;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) acc += poison[i];  // keeps the stores alive
+    const uint64_t t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < spin) {}
+    if (acc == 0x12345678u && seed == 0u) poison[0] = acc;
+}
+int launch_lds_poison(uint32_t seed, hipStream_t s)
+{
+    int dev = 0, n_cu = 0, max_lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || max_lds <= 0) return -1;
+    // all of the CU's LDS for one workgroup (gfx950: 160 KiB); above the default 64 KiB the limit has to be raised explicitly
+    if (hipFuncSetAttribute((const void *)k_lds_poison, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds) != hipSuccess) {
+        (void)hipGetLastError();
+        max_lds = 64 * 1024;
+    }
+    hipLaunchKernelGGL(k_lds_poison, dim3((uint32_t)(4 * n_cu)), dim3(256), (size_t)max_lds, s, seed, (uint32_t)max_lds / 4u, 40000u);
+    return max_lds;
+}
+
 }  // namespace sr

@@ -23,6 +23,7 @@ enum DevHook {
     kHookMultiAllowDup,   // "multi_allow_dup": sr_multi_create accepts one device several times (1-GPU tests over the RCCL double)
     kHookDtwDebug,        // "dtw_debug":   print the k_dtw_lds geometry when a store is set
     kHookCellsLiteral,    // "cells_literal": k_dtw_cells walks every pair literally (the fallback of walks that leave the band)
+    kHookMagCheapOff,     // "mag_cheap_off": sr_create behaves as if the device sweep of the cheap magnitude form had failed (bound 0)
     kHookCount
 };
 #ifdef SR_TESTING
@@ -80,6 +81,7 @@ struct MfccArgs {
     uint32_t small_tiles;   // 0: 64-frame work items; 1 / 2: the 16- / 4-frame forms of k_mfcc for underfilled launches (tiles counts those)
     uint32_t n_items;       // B * tiles
     uint32_t grid_cap;      // resident workgroups of k_mfcc on this device (0 = default)
+    uint32_t mag_cheap_max; // k_mfcc: largest re^2 + im^2 whose magnitude may take the uncorrected v_sqrt_f32 (kMagCheapMax where sr_create's sweep of this device confirmed it, else 0)
     uint32_t frame_len;     // 160 -> k_mfcc (reference front end), 320 -> k_mfcc_ext (extension)
     uint32_t generic;       // 1 -> k_mfcc_gen (GENERIC front end): the four fields below are only read there
     uint32_t hop, n_mel, n_coef;
@@ -166,6 +168,7 @@ void launch_unpack12(const void *packed, uint64_t row_bytes, uint16_t *out, uint
 void launch_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const DevTables &t, hipStream_t s);
 // diagnostics: fused Mel filterbank term vs the reference's u32 expression, weights [tri_lo, tri_lo + n_tri), E <= e_max
 void launch_mel_term_sweep(uint32_t tri_lo, uint32_t n_tri, uint32_t e_max, unsigned long long *bad, hipStream_t s);
+int launch_lds_poison(uint32_t seed, hipStream_t s);  // k_misc.hip; returns the bytes of LDS each workgroup filled, < 0 on failure
 void launch_mag_fast_sweep(uint32_t n_max, unsigned long long *bad, uint32_t *first_bad, hipStream_t s);
 // get_dis (DTW.C:45-62) for n frame pairs
 void launch_get_dis(const int16_t *a, const int16_t *b, uint32_t *out, uint32_t n, hipStream_t s);

@@ -20,7 +20,8 @@ int set_error(int code, const std::string &msg)
 static std::atomic<int64_t> g_hooks[kHookCount];
 int64_t dev_hook(DevHook h) { return g_hooks[h].load(std::memory_order_relaxed); }
 static const char *const kHookNames[kHookCount] = {"dtw_u", "dtw_tie_g", "dtw_kc", "mfcc_grid", "perturb_log_thr",
-                                                   "log_thr_from_host", "multi_allow_dup", "dtw_debug", "cells_literal"};
+                                                   "log_thr_from_host", "multi_allow_dup", "dtw_debug", "cells_literal",
+                                                   "mag_cheap_off"};
 #endif
 }  // namespace sr
 
@@ -91,6 +92,7 @@ static int front_end_of(const sr_config *cfg, FrontEnd *fe)
 }
 
 int sr_log_table_mismatches(void) { return log_table_mismatches(); }
+uint32_t sr_mag_cheap_bound(const sr_engine *h) { return h ? h->mag_cheap_max : 0u; }
 
 // 1 in the -DSR_TESTING build (development hooks compiled in), 0 in the product library
 int sr_testing_build(void)
@@ -287,6 +289,37 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     h->dev.hamm_pk = (const uint32_t *)(base + parts[13].off);
     h->dev.tri_even_m = (const uint32_t *)(base + parts[14].off);
     h->dev.tri_odd_m = (const uint32_t *)(base + parts[15].off);
+    // The cheap magnitude form of k_mfcc's QUIET / MID tiers rests on a property of this chip's v_sqrt_f32, so it is checked
+    // here, on the device the engine will run on, over the WHOLE range it is used on (70 172 values, microseconds): any
+    // difference from the exactly corrected root and every frame takes the exact form (bound 0) -- parity never depends on a
+    // stepping or a microcode revision the test suite has not seen.  sr_mag_cheap_bound() reports the outcome.
+    if (!h->generic && h->frame_len == (uint32_t)kFrameLen) {
+        uint32_t *sw = nullptr;
+        const uint32_t init[4] = {0, 0, 0xFFFFFFFFu, 0};
+        uint32_t back[4] = {1, 0, 0, 0};
+        hipError_t se = hipMalloc(&sw, sizeof init);
+        if (se == hipSuccess) se = hipMemcpy(sw, init, sizeof init, hipMemcpyHostToDevice);
+        if (se == hipSuccess) {
+            launch_mag_fast_sweep(kMagCheapMax, (unsigned long long *)sw, sw + 2, nullptr);
+            se = hipGetLastError();
+        }
+        if (se == hipSuccess) se = hipMemcpy(back, sw, sizeof back, hipMemcpyDeviceToHost);
+        if (sw) (void)hipFree(sw);
+        if (se != hipSuccess) {
+            sr_destroy(h);
+            return fail(SR_ERR_HIP, std::string("magnitude sweep: ") + hipGetErrorString(se));
+        }
+        const bool ok = back[0] == 0 && back[1] == 0;
+        h->mag_cheap_max = ok ? kMagCheapMax : 0u;
+        if (dev_hook(kHookMagCheapOff)) h->mag_cheap_max = 0;  // development hook: exercise the fallback
+        if (!ok) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "sr_create: v_sqrt_f32 magnitude differs from the exact form at n = %u on this device; "
+                          "every frame takes the exact root", back[2]);
+            std::fprintf(stderr, "%s\n", msg);
+            (void)fail(SR_OK, msg);
+        }
+    }
     if (h->s_pcnt.reserve(kPairCounters) != SR_OK || hipMemset(h->s_pcnt.p, 0, kPairCounters * sizeof(uint32_t)) != hipSuccess) {
         sr_destroy(h);
         return fail(SR_ERR_HIP, "pair counters");

@@ -88,6 +88,7 @@ struct sr_engine {
     sr_config cfg;
     int device = 0;
     uint32_t noise_len = 0, atap_frm = 0;
+    uint32_t mag_cheap_max = 0;  // kMagCheapMax once the device sweep at sr_create has confirmed the cheap magnitude form on this chip, else 0
     uint32_t mfcc_tile = 64, mfcc_tile_mid = 64, mfcc_tile_small = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item (batch form / the two forms for underfilled launches), resident workgroups
     uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension, or the generic front end's framing
     uint32_t nc = 12, n_mel = 24;                // s16 per feature row (n_coef), Mel filters

@@ -567,6 +567,19 @@ int sr_mag_fast_sweep(sr_engine *h, uint32_t n_max, uint64_t out[2])
     return SR_OK;
 }
 
+// diagnostics: overwrite the local data share of every compute unit with a seeded pattern (on `stream`, asynchronous); the
+// suite launches it between calls so that no kernel can pass by reading what its own previous workgroups left in LDS
+int sr_lds_poison(sr_engine *h, uint32_t seed, void *stream, uint32_t *bytes_per_cu)
+{
+    if (!h) return fail(SR_ERR_BAD_ARG, "null argument");
+    ENTER_DEVICE(h);
+    const int n = launch_lds_poison(seed, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    if (n < 0) return fail(SR_ERR_HIP, "sr_lds_poison: device attribute query failed");
+    if (bytes_per_cu) *bytes_per_cu = (uint32_t)n;
+    return SR_OK;
+}
+
 // diagnostics: k_mfcc's fused filterbank term against the reference's expression, see k_mel_term_sweep
 int sr_mel_term_sweep(sr_engine *h, uint32_t tri_lo, uint32_t tri_hi, uint32_t e_max, uint64_t *mismatches)
 {
@@ -645,6 +658,52 @@ int engine_dtw_limit(sr_engine *h, uint16_t x, uint16_t y, int X1, int X2, int i
     HIP_TRY(hipMemcpy(out, h->s_u32a.p + 1, 1, hipMemcpyDeviceToHost));
     return SR_OK;
 }
+
+}  // namespace sr
+
+// Batched forms of the two small scalar symbols (the kernels get_dis() / dtw_limit() launch with n = 1), so that tests can
+// compare them with the reference object over whole grids in one launch.
+// get_dis (DTW.C:45-62) on n pairs of 12-coefficient rows
+int sr_get_dis_batch(sr_engine *h, const int16_t *a, const int16_t *b, uint32_t n, uint32_t *out)
+{
+    if (!h || !a || !b || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (n == 0) return SR_OK;
+    if (h->nc != (uint32_t)kCoef) return fail(SR_ERR_BAD_CONFIG, "sr_get_dis_batch: 12-coefficient front ends only");
+    ENTER_DEVICE(h);
+    if (int rc_ord_ = order_after_scratch_users(h, nullptr)) return rc_ord_;
+    int rc;
+    if ((rc = h->s_mfcc.reserve((size_t)2 * n * kCoef))) return rc;
+    if ((rc = h->s_u32a.reserve(n))) return rc;
+    HIP_TRY(hipMemcpy(h->s_mfcc.p, a, (size_t)n * kCoef * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->s_mfcc.p + (size_t)n * kCoef, b, (size_t)n * kCoef * 2, hipMemcpyHostToDevice));
+    launch_get_dis(h->s_mfcc.p, h->s_mfcc.p + (size_t)n * kCoef, h->s_u32a.p, n, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, h->s_u32a.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+// dtw_limit (DTW.C:76-109) on n points (x, y) for the statics a dtw() call of in_frames against mdl_frames leaves behind
+// (DTW.C:129-130, 141-142: X1 = (2 mdl - in) / 3, X2 = (4 in - 2 mdl) / 3 as u16); out[i] = 1: outside
+int sr_dtw_limit_batch(sr_engine *h, const uint16_t *xy, uint32_t n, uint32_t in_frames, uint32_t mdl_frames, uint8_t *out)
+{
+    if (!h || !xy || !out) return fail(SR_ERR_BAD_ARG, "null argument");
+    if (n == 0) return SR_OK;
+    if (in_frames > 65535u || mdl_frames > 65535u) return fail(SR_ERR_BAD_ARG, "sr_dtw_limit_batch: frame counts are u16 (DTW.C:65-68)");
+    ENTER_DEVICE(h);
+    if (int rc_ord_ = order_after_scratch_users(h, nullptr)) return rc_ord_;
+    int rc;
+    const size_t words = ((size_t)n * 4 + 3) / 4 + ((size_t)n + 3) / 4;
+    if ((rc = h->s_u32a.reserve(words))) return rc;
+    uint8_t *d_out = (uint8_t *)(h->s_u32a.p + n);
+    HIP_TRY(hipMemcpy(h->s_u32a.p, xy, (size_t)n * 4, hipMemcpyHostToDevice));
+    const int X1 = (int)(uint16_t)((2 * (int)mdl_frames - (int)in_frames) / 3), X2 = (int)(uint16_t)((4 * (int)in_frames - 2 * (int)mdl_frames) / 3);
+    launch_dtw_limit((const uint16_t *)h->s_u32a.p, d_out, n, X1, X2, (int)in_frames, (int)mdl_frames, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+namespace sr {
 
 int engine_vad_with_atap(sr_engine *h, const uint16_t *pcm, uint32_t buf_len, const sr_atap *atap, sr_vad_rec *rec)
 {

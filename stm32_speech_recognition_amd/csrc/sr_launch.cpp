@@ -96,6 +96,7 @@ MfccArgs mfcc_args(const sr_engine *h, const uint16_t *d_pcm, uint64_t pcm_strid
         }
     }
     a.grid_cap = h->mfcc_grid_cap;
+    a.mag_cheap_max = h->mag_cheap_max;
     a.frame_len = h->frame_len;
     a.n_items = B * a.tiles;
     a.generic = h->generic ? 1u : 0u;

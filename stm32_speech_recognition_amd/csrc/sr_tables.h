@@ -44,6 +44,12 @@ constexpr uint32_t kMelFusedMaxE = (1u << 28) / 100u;  // 2 684 354  (|X|*10 <= 
 // sr_mag_fast_sweep, repeated by every -m gpu run): 10*sqrt(26843) = 1638.38.  One test on n serves both fast forms of k_mfcc.
 constexpr uint32_t kMagSmallMax = 26843;
 static_assert(1638u * 1638u <= kMelFusedMaxE && 100ull * (kMagSmallMax + 1) < 1639ull * 1639ull, "quiet-frame bound");
+// re^2 + im^2 of a bin up to which the uncorrected v_sqrt_f32 gives the same (u32)(sqrtf(n)*10) as the exact root ON gfx950 (the
+// first difference is at n = 70 172): k_mfcc's MID tier (round 6: cheap magnitude, literal filterbank term).  A property of the
+// chip's v_sqrt_f32, not of the arithmetic: sr_create sweeps [0, kMagCheapMax] on the device it runs on (k_mag_fast_sweep) and
+// hands the kernel a bound of 0 -- every frame then takes the exactly corrected root -- if the sweep finds a difference.
+constexpr uint32_t kMagCheapMax = 70171;
+static_assert(kMagSmallMax <= kMagCheapMax, "the quiet tier lies inside the cheap-magnitude range");
 constexpr uint32_t kMelTriMax = 1599;                  // largest weight whose multiplier fits 32 bits
 constexpr uint32_t mel_fused_multiplier(uint32_t tri) { return (uint32_t)((((uint64_t)tri << 28) + 99u) / 100u); }
 

@@ -160,6 +160,17 @@ class Engine:
         if rc != 0:
             raise SrError(f"sr_engine error {rc}: {self.L.sr_last_error().decode()}")
 
+    def mag_cheap_bound(self):
+        """sr_mag_cheap_bound: 70171 when sr_create's sweep of this device confirmed the frame kernel's cheap magnitude form, else 0"""
+        self.L.sr_mag_cheap_bound.restype = C.c_uint32
+        return int(self.L.sr_mag_cheap_bound(self.h))
+
+    def lds_poison(self, seed, stream=None):
+        """sr_lds_poison: overwrite every CU's local data share with a seeded pattern; returns the bytes filled per workgroup"""
+        n = C.c_uint32(0)
+        self._check(self.L.sr_lds_poison(self.h, C.c_uint32(seed), C.c_void_p(stream), C.byref(n)))
+        return n.value
+
     def close(self):
         if getattr(self, "h", None):
             if not getattr(self, "_borrowed", False):

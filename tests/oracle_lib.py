@@ -159,6 +159,29 @@ class Oracle:
         n = self.L.sr_oracle_mfcc(self.h, _p(pcm), C.c_int32(start), C.c_int32(end), C.byref(atap), _p(out))
         return n, out[:n].copy()
 
+    def frame_peaks(self, pcm, start, end, atap):
+        """diagnostic: largest re^2 + im^2 of every frame of the segment (which tier of k_mfcc a frame falls into)"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.uint16)
+        out = np.zeros(self.max_frames + 1, dtype=np.uint32)
+        self.L.sr_oracle_frame_peaks.restype = C.c_uint32
+        n = self.L.sr_oracle_frame_peaks(self.h, _p(pcm), C.c_int32(start), C.c_int32(end), C.byref(atap), _p(out),
+                                         C.c_uint32(len(out)))
+        return out[:n].copy()
+
+    def frame_tiers(self, pcm_batch):
+        """fractions of the frames of segment 0 of each capture in k_mfcc's QUIET / MID / LOUD tier (csrc/sr_tables.h:
+        kMagSmallMax = 26 843, kMagCheapMax = 70 171) and the number of frames counted"""
+        pk = []
+        for row in pcm_batch:
+            rc, a = self.noise_atap(row)
+            seg = self.vad(row, a)
+            if rc == 0 and seg[0] >= 0 and seg[1] >= 0:
+                pk.append(self.frame_peaks(row, int(seg[0]), int(seg[1]), a))
+        pk = np.concatenate(pk) if pk else np.zeros(0, np.uint32)
+        n = max(len(pk), 1)
+        return {"quiet": float((pk <= 26843).sum() / n), "mid": float(((pk > 26843) & (pk <= 70171)).sum() / n),
+                "loud": float((pk > 70171).sum() / n), "frames": int(len(pk))}
+
     def get_dis(self, a, b):
         a = np.ascontiguousarray(a, dtype=np.int16)
         b = np.ascontiguousarray(b, dtype=np.int16)

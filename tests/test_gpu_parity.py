@@ -235,8 +235,11 @@ def test_full_path_matches_oracle(T, B, K):
     eng.close()
 
 
-def test_full_path_matches_reference_objects():
-    """Tier (i) at the BENCHMARK shape inside the GPU suite: the HIP path against the reference's OWN VAD.C / MFCC.C / DTW.C
+@pytest.mark.parametrize("gain", [1.0, 2.4, 4.0])
+def test_full_path_matches_reference_objects(gain):
+    """(gain: the generator's speech amplitude -- 1.0 = bench.py's headline, 2.4 = SURVEY.md 8(d)'s 200-600, 4.0 = most frames in
+    the frame kernel's LOUD tier; the three tiers of k_mfcc's magnitude / filterbank stage, DESIGN.md 3.2, are all on the path.)
+    Tier (i) at the BENCHMARK shape inside the GPU suite: the HIP path against the reference's OWN VAD.C / MFCC.C / DTW.C
     objects (oracle/_ref/libsr_ref320.so: compiled from the reference tree with the one constant that caps a record at
     119 frames raised to 320, MFCC.H:15-16; oracle/Makefile) -- 256-frame utterances x 100 templates of 192..320 frames,
     one template outside the 1/2..2x gate of DTW.C:133, one erased slot, some captures with ragged segments and one
@@ -252,7 +255,7 @@ def test_full_path_matches_reference_objects():
     ref = ol.RefLib320()
     tfr = [int(v) for v in rng.integers(192, 321, K)]
     tfr[3] = 120   # 2 * 120 < 256: in > 2 * mdl -> dis_err (DTW.C:133-137)
-    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(K) % 20, tfr, seed=77, bank=bank, S=synth.buf_len_for(320)))
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(K) % 20, tfr, seed=77, bank=bank, S=synth.buf_len_for(320), gain=gain))
     tm = np.zeros((K, 321, 12), np.int16)
     for k in range(K):
         a, seg = ref.vad(tp[k])
@@ -263,14 +266,22 @@ def test_full_path_matches_reference_objects():
     valid = np.ones(K, np.uint8)
     valid[5] = 0   # erased flash slot: save_sign != 12345 (main.c:283)
     S = synth.buf_len_for(T)
-    pcm_t = synth.make_utterances(rng.integers(0, 20, B), [T] * B, seed=99, bank=bank, S=S, device="cuda:0")
-    noisy = synth.make_utterances(rng.integers(0, 20, 8), [T - 20] * 8, seed=5, bank=bank, S=S, quiet_sigma=8.0)
+    pcm_t = synth.make_utterances(rng.integers(0, 20, B), [T] * B, seed=99, bank=bank, S=S, device="cuda:0", gain=gain)
+    noisy = synth.make_utterances(rng.integers(0, 20, 8), [T - 20] * 8, seed=5, bank=bank, S=S, quiet_sigma=8.0, gain=gain)
     pcm_t[:8] = noisy.to("cuda:0")
     pcm_t[8] = 2048
     eng = Engine(max_frames=320, device=0)
+    assert eng.mag_cheap_bound() == 70171   # sr_create's sweep of this device confirmed the cheap magnitude form (else: 0, exact roots)
     eng.set_templates_dense(tm, tf, valid)
     out = eng.recognize_dev(pcm_t, eng.alloc_outputs(B, "cuda:0"))
     torch.cuda.synchronize()
+    tiers = ol.Oracle(max_frames=320).frame_tiers(synth.as_u16_numpy(pcm_t[16:48]))
+    if gain == 1.0:
+        assert tiers["quiet"] > 0.9
+    elif gain == 2.4:
+        assert min(tiers["quiet"], tiers["mid"], tiers["loud"]) > 0.1, tiers   # every tier carries a real share of the frames
+    else:
+        assert tiers["loud"] > 0.5, tiers
     res = results_from_torch(out["results"])
     gmf = out["mfcc"].cpu().numpy()
     gsc = out["scores"].cpu().numpy().view(np.uint32)
@@ -880,6 +891,221 @@ def test_concurrent_device_and_host_calls_soak():
             raise AssertionError(f"call {calls}: the device call differs at utterances {where} (nb {nb}, b0 {b0})")
         assert (r["best_tpl"][0], r["min_dis"][0], r["frm_num"][0], r["status"][0]) == tuple(er[b]), (calls, b)
     assert calls > 200, calls
+    eng.close()
+
+
+def _soak_setup(ext=False, n=2048):
+    """engine + 80-slot store + n captures resident in HBM + the outputs of ONE quiet call (the batch kernels, nothing else on
+    the chip): what every later call of a soak must reproduce byte for byte"""
+    from stm32_speech_recognition_amd import Engine
+    rate, cfg, S = (2, dict(fs=16000, nfft=512, n_mel=40), 32000) if ext else (1, {}, 16000)
+    eng = Engine(max_frames=119, device=0, **cfg)
+    bank = synth.word_bank(25)
+    rng = np.random.default_rng(12 + ext)
+    tp = synth.as_u16_numpy(synth.make_utterances(np.arange(80) % 25, rng.integers(40, 120, 80), seed=8, bank=bank, S=S, rate=rate))
+    store, st = eng.train_store(tp, np.arange(80), n_slots=80)
+    assert (st == 0).all()
+    eng.set_templates_store(store)
+    dev = torch.device("cuda", 0)
+    dpcm = synth.make_utterances(rng.integers(0, 25, n), rng.integers(30, 119, n), seed=9, bank=bank, S=S, device=dev, rate=rate)
+    eng.set_small_launch(1)
+    o = eng.recognize_dev(dpcm, eng.alloc_outputs(n, dev, mfcc=True, vad=True))
+    torch.cuda.synchronize()
+    want = {k: o[k].clone() for k in ("results", "scores", "mfcc", "vad")}
+    eng.set_small_launch(0)
+    return eng, dpcm, want, rng
+
+
+def _soak_compare(oo, want, b0, nb, what):
+    if all(torch.equal(oo[k].reshape(nb, -1), want[k][b0:b0 + nb].reshape(nb, -1)) for k in ("scores", "results", "mfcc", "vad")):
+        return
+    where = {}
+    for k in ("vad", "mfcc", "scores", "results"):
+        d = (oo[k].reshape(nb, -1) != want[k][b0:b0 + nb].reshape(nb, -1)).any(1)
+        where[k] = torch.nonzero(d).ravel()[:4].tolist()
+    raise AssertionError(f"{what}: differs from the quiet run at utterances {where} (nb {nb}, b0 {b0})")
+
+
+@pytest.mark.parametrize("front", ["ref", "ext"])
+def test_lds_poison_between_calls_changes_nothing(front):
+    """Race-class test 1 (round 6).  The local data share of EVERY compute unit is overwritten with a seeded pattern
+    (sr_lds_poison: one 160 KiB workgroup per CU) before each call; then a batch-sized call (k_vad, the frame kernel, k_dtw_lds)
+    and a call small enough for every small-launch form, in all four small-launch modes, must give the bytes of the quiet
+    run.  A kernel that reads LDS it has not written -- round 5's defect: a table filled behind the last barrier -- passes
+    every other parity test as long as the CU's previous tenant was a workgroup of the same kernel; after the poison it
+    cannot.  Fails on the -DSR_INJECT_LDS_RACE build (profiles/experiments/RESULTS.md, round 6)."""
+    import ctypes as C
+    eng, dpcm, want, rng = _soak_setup(ext=(front == "ext"), n=1536)
+    dev = dpcm.device
+    nbytes = C.c_uint32(0)
+    n_small = 6
+    calls = 0
+    for rep in range(3):
+        for mode in (1, 2, 3, 0):
+            eng.set_small_launch(mode)
+            for b0, nb in ((0, 1536), (int(rng.integers(0, 1536 - n_small)), n_small)):
+                assert eng.L.sr_lds_poison(eng.h, C.c_uint32(0xC0FFEE + calls), None, C.byref(nbytes)) == 0
+                oo = eng.recognize_dev(dpcm[b0:b0 + nb], eng.alloc_outputs(nb, dev, mfcc=True, vad=True))
+                torch.cuda.synchronize()
+                calls += 1
+                _soak_compare(oo, want, b0, nb, f"{front} front end, small-launch mode {mode}, {nb} captures after an LDS poison")
+    assert nbytes.value == 160 * 1024, nbytes.value   # the poison really covers a CU's whole LDS
+    eng.set_small_launch(0)
+    eng.close()
+
+
+def test_two_device_calls_and_a_host_call_in_flight_soak():
+    """Race-class test 2 (round 6): THREE calls of one engine in flight for ~10 s -- two device calls on two caller streams
+    (1 229-2 048 and 300-700 captures: batch kernels and, for the second, a frame kernel launch that leaves the chip partly
+    empty) and an unsynchronised one-capture host call on the engine's internal stream.  Everything the device calls write must
+    equal the quiet run; the host call's record too.  Fails on the -DSR_INJECT_LDS_RACE build."""
+    import time
+    eng, dpcm, want, rng = _soak_setup()
+    n = dpcm.shape[0]
+    dev = dpcm.device
+    hpcm = dpcm.cpu().numpy().view(np.uint16)
+    er = want["results"].cpu().numpy().view(np.uint32).reshape(n, 4)
+    eng.set_pipeline(streams=3, min_chunk=4096, max_chunks=12)
+    s1, s2, s3 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    hog_a, hog_b = torch.empty(96 << 20, dtype=torch.int32, device=dev), torch.empty(96 << 20, dtype=torch.int32, device=dev)
+    budget = float(os.environ.get("SR_SOAK_SECONDS", "10"))
+    t0, calls = time.time(), 0
+    while time.time() - t0 < budget:
+        na, nb = int(rng.integers(1229, 2049)), int(rng.integers(300, 701))
+        a0, b0 = int(rng.integers(0, n - na + 1)), int(rng.integers(0, n - nb + 1))
+        oa, ob = eng.alloc_outputs(na, dev, mfcc=True, vad=True), eng.alloc_outputs(nb, dev, mfcc=True, vad=True)
+        if calls & 1:  # every other round under HBM pressure (a 384 MB copy on a third stream: table loads of the kernels get slow)
+            with torch.cuda.stream(s3):
+                hog_b.copy_(hog_a, non_blocking=True)
+        eng.recognize_dev(dpcm[a0:a0 + na], oa, stream=s1.cuda_stream)
+        eng.recognize_dev(dpcm[b0:b0 + nb], ob, stream=s2.cuda_stream)
+        b = int(rng.integers(0, n))
+        r = eng.recognize(hpcm[b:b + 1], want_scores=False, want_mfcc=False, want_vad=False)["results"]
+        torch.cuda.synchronize()
+        calls += 1
+        _soak_compare(oa, want, a0, na, f"call {calls}, first device call")
+        _soak_compare(ob, want, b0, nb, f"call {calls}, second device call")
+        assert (r["best_tpl"][0], r["min_dis"][0], r["frm_num"][0], r["status"][0]) == tuple(er[b]), (calls, b)
+    assert calls > 100, calls
+    eng.close()
+
+
+def test_concurrent_calls_soak_16k_front_end():
+    """Race-class test 3 (round 6): the two-calls-in-flight soak of the reference front end above, on the 16 kHz / 512-point /
+    40-Mel EXTENSION front end (k_vad<320,160>, k_mfcc_ext; no reference counterpart -- the comparison is with the engine's own
+    quiet run), ~10 s.  Fails on the -DSR_INJECT_LDS_RACE build."""
+    import time
+    eng, dpcm, want, rng = _soak_setup(ext=True, n=1536)
+    n = dpcm.shape[0]
+    dev = dpcm.device
+    hpcm = dpcm.cpu().numpy().view(np.uint16)
+    er = want["results"].cpu().numpy().view(np.uint32).reshape(n, 4)
+    side = torch.cuda.Stream(device=dev)
+    budget = float(os.environ.get("SR_SOAK_SECONDS", "10"))
+    t0, calls = time.time(), 0
+    while time.time() - t0 < budget:
+        nb = int(rng.integers(900, n + 1))
+        b0 = int(rng.integers(0, n - nb + 1))
+        oo = eng.alloc_outputs(nb, dev, mfcc=True, vad=True)
+        eng.recognize_dev(dpcm[b0:b0 + nb], oo, stream=side.cuda_stream)
+        b = int(rng.integers(0, n))
+        r = eng.recognize(hpcm[b:b + 1], want_scores=False, want_mfcc=False, want_vad=False)["results"]
+        torch.cuda.synchronize()
+        calls += 1
+        _soak_compare(oo, want, b0, nb, f"call {calls}")
+        assert (r["best_tpl"][0], r["min_dis"][0], r["frm_num"][0], r["status"][0]) == tuple(er[b]), (calls, b)
+    assert calls > 100, calls
+    eng.close()
+
+
+def test_dtw_limit_symbol_exhaustive_against_reference_object():
+    """dtw_limit (DTW.C:76-109) through the C ABI against the REFERENCE OBJECT's own dtw_limit (oracle/_ref/libsr_ref.so exports
+    it), for 64 random (in, mdl) length pairs -- the reference's dtw() call sets its file statics X1 / X2 / in / mdl
+    (DTW.C:65-68, 129-142), the library gets the same lengths -- and EVERY point x, y <= 121 (14 884 per pair, one launch each
+    through sr_dtw_limit_batch = the kernel the scalar symbol launches); the scalar symbol itself on 40 random points of
+    eight of the pairs after the library's own dtw() call.  Includes pairs the length gate rejects: dtw() returns before
+    X1 / X2 are updated (DTW.C:133-137), so dtw_limit keeps answering for the PREVIOUS pair's X1 / X2 with the new lengths."""
+    import ctypes as C
+    from stm32_speech_recognition_amd import Engine, compat
+    if not ol.RefLib.available():
+        pytest.fail("oracle/_ref/libsr_ref.so is missing: build it where /root/reference exists (make -C oracle)")
+    ref = ol.RefLib()
+    ref.L.dtw_limit.restype = C.c_uint8
+    eng = Engine(max_frames=119, device=0)
+    rng = np.random.default_rng(76109)
+    xs, ys = np.meshgrid(np.arange(122, dtype=np.uint16), np.arange(122, dtype=np.uint16), indexing="ij")
+    xy = np.ascontiguousarray(np.stack([xs.ravel(), ys.ravel()], 1))
+    rows = rng.integers(-300, 300, (2, 120, 12)).astype(np.int16)
+    lens = [(int(a), int(b)) for a, b in rng.integers(1, 120, (56, 2))] + [(1, 1), (1, 2), (2, 1), (119, 119), (119, 60), (60, 119),
+                                                                           (50, 60), (100, 51)]
+    n_gate = 0
+    for i, (n_in, n_mdl) in enumerate(lens):
+        gated = n_in > 2 * n_mdl or 2 * n_in < n_mdl
+        n_gate += gated
+        fa, fb = ref.make_ftr(rows[0], n_in), ref.make_ftr(rows[1], n_mdl)
+        ref.dtw(fa, fb)
+        want = np.fromiter((ref.L.dtw_limit(C.c_uint16(int(x)), C.c_uint16(int(y))) for x, y in xy), np.uint8, len(xy))
+        if gated:
+            continue   # the statics are a mixture of two calls there; covered through the scalar symbol below
+        got = np.zeros(len(xy), np.uint8)
+        eng._check(eng.L.sr_dtw_limit_batch(eng.h, xy.ctypes.data_as(C.c_void_p), C.c_uint32(len(xy)), C.c_uint32(n_in),
+                                            C.c_uint32(n_mdl), got.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(got, want), (n_in, n_mdl, xy[np.nonzero(got != want)[0][:5]])
+    assert n_gate >= 4
+    # the scalar symbol after the library's own dtw(), same call sequence on both sides (gated pairs included: stale X1 / X2)
+    for (n_in, n_mdl) in [(50, 60)] + lens[:4] + lens[-4:] + [(10, 100), (100, 10), (70, 71)]:
+        ref.dtw(ref.make_ftr(rows[0], n_in), ref.make_ftr(rows[1], n_mdl))
+        compat.dtw(compat.make_ftr(rows[0], n_in), compat.make_ftr(rows[1], n_mdl))
+        for x, y in rng.integers(0, 122, (40, 2)):
+            assert compat.dtw_limit(int(x), int(y)) == ref.L.dtw_limit(C.c_uint16(int(x)), C.c_uint16(int(y))), (n_in, n_mdl, x, y)
+    eng.close()
+
+
+def test_get_dis_symbol_against_reference_object():
+    """get_dis (DTW.C:45-62) through the C ABI against the REFERENCE OBJECT's get_dis on 10 000 random row pairs at five
+    scales, 2 000 full-scale pairs (u32 wrap of the sum of squares), and 4 000 pairs built to land on perfect squares and
+    their neighbours (where sqrtf's rounding decides the integer); the scalar symbol itself on 200 of them."""
+    import ctypes as C
+    from stm32_speech_recognition_amd import Engine, compat
+    if not ol.RefLib.available():
+        pytest.fail("oracle/_ref/libsr_ref.so is missing: build it where /root/reference exists (make -C oracle)")
+    ref = ol.RefLib()
+    ref.L.get_dis.restype = C.c_uint32
+    rng = np.random.default_rng(4562)
+    parts_a, parts_b = [], []
+    for scale in (3, 40, 600, 5000, 32767):
+        parts_a.append(rng.integers(-scale, scale + 1, (2000, 12)))
+        parts_b.append(rng.integers(-scale, scale + 1, (2000, 12)))
+    fs = rng.choice(np.array([-32768, 32767, -32767, 0, 1, -1]), (2000, 12))
+    parts_a.append(fs)
+    parts_b.append(-fs + rng.integers(-1, 2, (2000, 12)))
+    # perfect squares: a - b = (k, 0, ..., 0) gives the sum k^2; one more coefficient differing by 1 gives k^2 + 1; and
+    # (k, j, 0...) sums that sit just below the next square
+    k = rng.integers(1, 65536, 4000)
+    a = np.zeros((4000, 12), np.int64)
+    b = np.zeros((4000, 12), np.int64)
+    a[:, 0] = k // 2
+    b[:, 0] = k // 2 - k
+    a[1000:2000, 1] = 1
+    j = np.sqrt(2 * k[2000:] + 1).astype(np.int64)
+    a[2000:3000, 1] = np.clip(j[:1000], 0, 32767)
+    a[3000:, 1] = np.clip(j[1000:] - 1, 0, 32767)
+    parts_a.append(a)
+    parts_b.append(b)
+    A = np.ascontiguousarray(np.clip(np.concatenate(parts_a), -32768, 32767).astype(np.int16))
+    Bm = np.ascontiguousarray(np.clip(np.concatenate(parts_b), -32768, 32767).astype(np.int16))
+    n = len(A)
+    want = np.fromiter((ref.L.get_dis(A[i].ctypes.data_as(C.c_void_p), Bm[i].ctypes.data_as(C.c_void_p)) for i in range(n)), np.uint32, n)
+    eng = Engine(max_frames=119, device=0)
+    got = np.zeros(n, np.uint32)
+    eng._check(eng.L.sr_get_dis_batch(eng.h, A.ctypes.data_as(C.c_void_p), Bm.ctypes.data_as(C.c_void_p), C.c_uint32(n),
+                                      got.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:8]
+    d = (A.astype(np.int64) - Bm.astype(np.int64)) ** 2
+    assert (d.sum(1) >= 1 << 32).any()   # the u32 wrap of DTW.C:56-58 is on the path
+    assert (np.sqrt(d[12000:13000].sum(1).astype(np.float64)) % 1 == 0).all()   # the perfect squares are perfect squares
+    for i in rng.integers(0, n, 200):
+        assert compat.get_dis(A[i], Bm[i]) == want[i], i
     eng.close()
 
 
