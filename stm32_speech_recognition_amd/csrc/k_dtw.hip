@@ -363,6 +363,9 @@ template <class F>  // F = Dtw12 / Dtw16: the row format
 __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 {
     typedef typename F::Row Row;
+#ifdef SR_DTW_PRIO
+    __builtin_amdgcn_s_setprio(SR_DTW_PRIO);  // experiment (RESULTS.md round 6): issue priority over co-resident frame-kernel waves
+#endif
     extern __shared__ __attribute__((aligned(16))) u32x2 smem2[];  // 8-byte typed: rows are read as ds_read_b64
     const uint32_t U = a.U, R = a.d.max_frames, K = a.d.K;
     // LDS (all of it dynamic): [tie-threshold table, tie_g bytes][rows][norms][frame counts].  The table comes FIRST, at
@@ -462,12 +465,18 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
         //   (x+1, y) inside    <=>  lbB <  y1  &&  y1 <= ubB1  (ubB1 = ub(x+1) + 1)
         //   (x+1, y+1) inside  <=>  lbB <= y1  &&  y1 <  ubB1
         const int c1s2 = c1s + 2;
+        const uint32_t tie_g1 = a.tie_g - 1;  // roots up to tie_g - 2 may be stepped by one and still find their threshold staged
         auto ub1_of = [&](int xx) { return (xx < X1) ? 2 * xx + 2 : ((xx + c1s2) >> 1); };
         auto lb_of = [&](int xx) { return (xx < X2) ? (xx >> 1) : 2 * xx + c2s; };
         int xB = 2, y1 = 2;  // xB = x + 1, y1 = y + 1; DTW.C:147-148
         int ubA1 = ub1_of(1), lbB = lb_of(2), ubB1 = ub1_of(2);
         uint64_t lost = 0;  // lane mask (kept scalar: OR-ed into the wave-uniform branch condition without touching the VALU)
-        uint32_t step = 1;  // u16 in the reference; cannot wrap here (steps < in_n + mdl_n <= 2R, R bounded by LDS)
+        // step (DTW.C:149, 186): u16 in the reference; cannot wrap here (steps < in_n + mdl_n <= 2R, R bounded by LDS).  Every lane
+        // of the wave enters the loop in the same trip, so a lane's step count is the wave's TRIP count when the lane leaves: the
+        // count lives on the scalar unit and a lane picks it up once, in the trip it leaves in (round 6; a per-lane v_add per
+        // step before)
+        uint32_t trips = 1, step = 1;
+        bool cont;
         do {
             // all three candidate squared distances, unconditionally: |m|^2 + |i|^2 + (-2m).i, the norm sum seeds
             // the dot2 accumulator (template rows are stored as -2m, see upload_templates)
@@ -476,7 +485,10 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t d_up = (uint32_t)F::dot_acc(nm, ci, (int)(F::nrm(nm) + F::nrm(ci)));  // (x, y+1):   get_dis(mdl+12, in)
             const uint32_t d_dg = (uint32_t)F::dot_acc(nm, ni, (int)(F::nrm(nm) + F::nrm(ni)));  // (x+1, y+1)
-            bool in_up = (y1 < ubA1), in_rt = (lbB < y1) & (y1 <= ubB1), in_dg = (lbB <= y1) & (y1 < ubB1);
+            // (x+1, y) can only leave through the LOWER bound: the current point is inside, y1 <= ub(x) + 1 = ubA1, and ub is
+            // non-decreasing in x (within each piece, and across the junction: ((X1 + c1s2) >> 1) >= 2 X1 + 2 because
+            // 3 X1 <= 2 mdl - in), so y1 <= ubB1 always holds for a lane that is not `lost` (round 6: one compare less)
+            bool in_up = (y1 < ubA1), in_rt = (lbB < y1), in_dg = (lbB <= y1) & (y1 < ubB1);
             // DTW.C:152-184 on the SQUARED candidates.  g(d) = (u32)sqrtf((float)d) is monotone, so the step cost is
             // g(min of the admissible candidates) -- one root instead of three -- and "min == right_up" / "min == up"
             // (the tie order of DTW.C:168-184) become g(q) == g(min)  <=>  q < T, T = first d with g(d) = g(min)+1.
@@ -487,7 +499,7 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             // minimum over the admissible candidates: one select and two v_min_u32 under the admissibility masks
             // (the masked-out candidates are never materialised; 0xFFFFFFFF when none is admissible)
             const uint64_t m_up = __builtin_amdgcn_ballot_w64(y1 < ubA1),
-                           m_rt = __builtin_amdgcn_ballot_w64(lbB < y1) & __builtin_amdgcn_ballot_w64(y1 <= ubB1),
+                           m_rt = __builtin_amdgcn_ballot_w64(lbB < y1),
                            m_dg = __builtin_amdgcn_ballot_w64(lbB <= y1) & __builtin_amdgcn_ballot_w64(y1 < ubB1);
             uint32_t m2;
             {
@@ -506,8 +518,11 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             }
             // the conditions that send the wave down the literal path are collected as LANE MASKS (ballots of the plain
             // compares, combined on the scalar unit): a bool OR-ed together and balloted afterwards costs two extra VALU ops
-            const float s0 = __builtin_amdgcn_sqrtf((float)m2);
-            uint32_t mn = (uint32_t)__int_as_float(__float_as_int(s0) + 1);  // floor(succ(s0)), see sqrt_floor_bracket
+            // Root of the step: v_sqrt_f32 is within one ulp of the correctly rounded root r of (float)m2, so floor(pred(s0)) is
+            // g = floor(r) or g - 1 (never above: pred(s0) <= r), and it is g - 1 exactly when m2 >= T(mn) -- the threshold the
+            // tie tests need anyway.  Round 6: replaces the two-sided bracket floor(succ(s0)) + "s0 > (float)mn" (a convert and a
+            // float compare per step, and a fused residual in the rare branch); swept over all 2^32 inputs through sr_math_diag.
+            uint32_t mn = sqrt_floor_low(m2);  // floor(pred(v_sqrt_f32)), sr_dtw_dev.h
             // T = first squared distance whose root is mn + 1 = mn*(mn + 2) + tie_delta[mn] (exact, sr_tables.cpp): a
             // candidate q >= m2 has the root mn  <=>  q < T.  One byte from the LDS table (address register = the root,
             // base = immediate offset), one add, one 24-bit multiply-add.  Roots >= tie_g -- which includes m2 = 0xFFFFFFFF,
@@ -519,14 +534,14 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(T) : "v"(mn), "v"(mp2), "v"(dl));
             }
             const bool tie_dg = in_dg & (d_dg < T), tie_up = in_up & (d_up < T);
-            // hard = the lanes that need the literal form; a failed bracket alone (about 5e-4 of the lane-steps, i.e. 3 % of the
-            // wave-steps) is settled exactly and cheaply inside the branch
-            const uint64_t hard = __builtin_amdgcn_ballot_w64(mn >= a.tie_g) | lost;
-            const uint64_t unsafe = __builtin_amdgcn_ballot_w64(!(s0 > (float)mn)) | hard;
+            // hard = the lanes that need the literal form (the root, or the root plus one, beyond the staged table); a root that
+            // came out one short (m2 >= T: squares and their close neighbours, about 5e-4 of the lane-steps) is settled inside the branch
+            const uint64_t hard = __builtin_amdgcn_ballot_w64(mn >= tie_g1) | lost;
+            const uint64_t unsafe = __builtin_amdgcn_ballot_w64(m2 >= T) | hard;
             bool mv_diag = tie_dg, mv_up = tie_up & !tie_dg;
 #ifdef SR_DTW_STATS
             {
-                const uint64_t mb = __builtin_amdgcn_ballot_w64(!(s0 > (float)mn)), mr = __builtin_amdgcn_ballot_w64(mn >= a.tie_g),
+                const uint64_t mb = __builtin_amdgcn_ballot_w64(m2 >= T), mr = __builtin_amdgcn_ballot_w64(mn >= tie_g1),
                                act = __builtin_amdgcn_ballot_w64(true);
                 if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)) == 0) {  // first active lane
                     atomicAdd(&g_dtw_stats[0], 1ull);
@@ -539,14 +554,11 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
             }
 #endif
             if (unsafe != 0ull && hard == 0ull) {
-                // Only the bracket is in doubt: mn = floor(succ(s0)) is the root or one too many.  With k = mn the exact test
-                // g(d) < k  <=>  fmaf(-k, pred(k), (float)d) <= 0 settles it (k - h, h = half an ulp below k, is where sqrt
-                // rounds up to k; (k - h)^2 = k*pred(k) + h^2 and (float)d - k*pred(k) is a multiple of 4h^2, so the sign
-                // of the fused residual decides; checked against the C expression for every k and d around k^2 and on
-                // 2e8 random d, tests/test_oracle.py).  Lanes whose bracket was safe keep their mn.  Then the threshold and
-                // the two tie tests once more.
-                const float kf = (float)mn, f2 = (float)m2;
-                if (__builtin_fmaf(-kf, __int_as_float(__float_as_int(kf) - 1), f2) <= 0.0f) mn -= 1;
+                // the root came out one short on some lanes (m2 >= T(mn) <=> g = mn + 1, exact: T is the first squared distance
+                // whose root is mn + 1): step it, look the next threshold up (mn + 1 < tie_g by the test above), the two tie tests
+                // once more.  Lanes with m2 < T keep everything.
+                const bool shrt = m2 >= T;
+                mn += shrt ? 1u : 0u;
                 const int dl = *(lds_c_i8 *)(uintptr_t)mn;
                 const uint32_t T2 = mn * (mn + 2) + (uint32_t)dl;
                 mv_diag = in_dg & (d_dg < T2);
@@ -597,8 +609,15 @@ __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
                     asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(lbB) : "v"(lb), "v"(la), "s"(m2x));
                 }
             }
-            step++;
-        } while (xB <= (int)in_n && y1 <= (int)mdl_n);  // DTW.C:188 (x < in && y < mdl)
+            trips++;
+            const bool cx = xB <= (int)in_n, cy = y1 <= (int)mdl_n;  // DTW.C:188 (x < in && y < mdl)
+            cont = cx && cy;
+            // (the ballots of the two plain compares, combined on the scalar unit: a ballot of `cont` costs a select and a compare)
+            if ((__builtin_amdgcn_ballot_w64(cx) & __builtin_amdgcn_ballot_w64(cy)) != __builtin_amdgcn_ballot_w64(true)) {  // wave-uniform: only trips in which a lane leaves
+                asm volatile("" : "+v"(step));  // (keeps the block a branch target: if-converted, it is three selects in EVERY trip)
+                if (!cont) step = trips;
+            }
+        } while (cont);
         score = dis / step;
     }
     a.d.scores[(size_t)b * K + a.tpl_orig[ks]] = score;

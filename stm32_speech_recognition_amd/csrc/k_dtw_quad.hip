@@ -242,10 +242,12 @@ bool dtw_quad_pick(const DtwArgs &a, uint32_t *pu, uint32_t *pk, size_t *lds)
     const size_t in_rec = quad::rec_bytes(a.max_frames, words), tp_rec = quad::rec_bytes(a.tpl_rows, words);
     static const uint32_t shapes[][2] = {{8, 8}, {4, 16}, {4, 8}, {2, 16}, {4, 4}, {2, 8}, {1, 16}, {2, 4}, {1, 8}, {1, 4}};
     uint64_t best = 0;
+    // LDS of the device the engine runs on (MI355X: 128 granules of 1 280 bytes per CU, all of which one workgroup may take)
+    const size_t cu_gran = (a.dev_lds_cu ? a.dev_lds_cu : 160u * 1024u) / 1280, wg_max = a.dev_lds_wg ? a.dev_lds_wg : 160u * 1024u;
     for (const auto &sh : shapes) {  // the most pairs resident per CU (workgroups by LDS granules, at most 8 of four waves)
         const size_t need = sh[0] * in_rec + sh[1] * tp_rec, gran = (need + 1279) / 1280;
-        if (gran > 120) continue;
-        const uint64_t per_cu = std::min<uint64_t>(8, 128 / gran) * sh[0] * sh[1];
+        if (gran + 8 > cu_gran || need > wg_max) continue;
+        const uint64_t per_cu = std::min<uint64_t>(8, cu_gran / gran) * sh[0] * sh[1];
         if (per_cu <= best) continue;
         best = per_cu;
         *pu = sh[0];
@@ -267,11 +269,15 @@ void launch_dtw_quad(const DtwArgs &a, hipStream_t s)
     uint32_t pu = 0, pk = 0;
     size_t lds = 0;
     if (!dtw_quad_pick(a, &pu, &pk, &lds)) return;  // callers check dtw_quad_fits first
+    if (lds > 64 * 1024) {  // above the default limit the kernel's dynamic LDS has to be allowed explicitly (once per instance)
+        const void *f = a.n_coef <= (uint32_t)kCoef ? (a.tpl_neg2_ok ? (const void *)k_dtw_quad<6, true> : (const void *)k_dtw_quad<6, false>)
+                                                    : (a.tpl_neg2_ok ? (const void *)k_dtw_quad<8, true> : (const void *)k_dtw_quad<8, false>);
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(a.dev_lds_wg ? a.dev_lds_wg : 160u * 1024u));
+    }
     const uint32_t gx = (a.K + pk - 1) / pk;
     for (uint32_t b0 = 0; b0 < a.B; b0 += 65535u * pu) {  // utterance groups are the grid's second dimension
         const uint32_t nb = a.B - b0 < 65535u * pu ? a.B - b0 : 65535u * pu;
         const dim3 grid(gx, (nb + pu - 1) / pu);
-        // (no hipFuncAttributeMaxDynamicSharedMemorySize: like k_dtw_lds / k_dtw_cells, launches above 64 KiB work as they are on ROCm)
         const dim3 blk(quad::kThreads);
         if (a.n_coef <= (uint32_t)kCoef) {
             if (a.tpl_neg2_ok) hipLaunchKernelGGL((k_dtw_quad<6, true>), grid, blk, lds, s, a, pu, pk, b0);

@@ -23,6 +23,12 @@ constexpr int kFramesPerWave = 16, kFramesPerWaveMid = 4, kFramesPerWaveSmall = 
 // 6 different frames x 12 different coefficients rows at the same column, and a stride of 24 folds those onto 4 banks
 constexpr int kMelPad = kMel + 1;
 // the windowed frame aliases the exchange area; the last 64 words hold the odd filters' lane offsets
+// Scratch order of the filterbank stage (energies, then the in-lane prefixes): bin j = 8 l + k sits in chunk k >> 2 (256 words
+// each) at 16-byte slot l ^ (4 (k >> 2)), word k & 3.  Lane l's two 16-byte reads and its prefix stores are then lane-contiguous
+// chunks (conflict-free; bin-major order put two lanes of every service group on the same banks), and the slot swizzle of
+// chunk 1 makes the magnitude stage's 4-byte stores -- 32 consecutive bins per service group = 4 lanes' slots x both chunks --
+// hit 32 different banks as well.
+__device__ __forceinline__ constexpr int mel_chunk_word(int j) { return 256 * ((j >> 2) & 1) + 4 * ((j >> 3) ^ (4 * ((j >> 2) & 1))) + (j & 3); }
 constexpr int mfcc_wave_lds_words(int fpw) { return kXchgWords + fpw * kMelPad + 64; }
 
 template <int kFPW>
@@ -32,11 +38,11 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_dctM[kCoef * kMelPad];
     __shared__ int s_dctS[kCoef * kMelPad];  // 32-bit: read with the wide LDS loads, no byte extraction
-    __shared__ u32x4 s_tw3[8 * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
+    __shared__ u32x4 s_tw3[kTw3Row * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
     __shared__ u32x4 s_tm[4 * 64];                 // filterbank multipliers of the lane's eight bins (both poly-lines)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *buf = smem + w * kWaveLdsWords;
-    uint16_t *xw = (uint16_t *)buf;  // windowed frame: consumed by the pass-1 gather before the exchange overwrites it
+    uint32_t *xw = buf;  // windowed frame, one word per sample: consumed by the pass-1 gather before the exchange overwrites it
     uint32_t *powb = buf + kXchgWords, *moff = powb + kFPW * kMelPad;
 
     // DCT term (MFCC.C:179): (s32)pow * dct / 100, truncated toward zero, with 0 <= pow <= 2218 (= (u32)(ln(2^32)*100))
@@ -56,7 +62,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     if (w == 0 && lane < 4) {
         const uint32_t *f = &tw.s3[0][0][0];
 #pragma unroll
-        for (int c = 0; c < 8; c++) s_tw3[lane * 8 + c] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
+        for (int c = 0; c < 8; c++) s_tw3[lane * kTw3Row + c] = u32x4{f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]};
     }
     if (w == 1 % kMfccWaves) store_tw32(s_tw5, lane, tw.s5);
     // triangle weights of bins 8*lane .. 8*lane+7 of both poly-lines as fused multipliers ceil(tri * 2^28 / 100)
@@ -101,8 +107,8 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         const int f_hi = (h == kMel - 1) ? kBins : (int)a.t.tri_cen[h + 1];
         const int ih = f_hi - 1, il = f_lo ? f_lo - 1 : 0, half = (h & 1) ? kBins : 0;
 #if SR_MEL_CHUNKED
-        p_hi = half + 256 * ((ih >> 2) & 1) + 4 * (ih >> 3) + (ih & 3), x_hi = ih >> 3;
-        p_lo = half + 256 * ((il >> 2) & 1) + 4 * (il >> 3) + (il & 3), x_lo = il >> 3;
+        p_hi = half + mel_chunk_word(ih), x_hi = ih >> 3;
+        p_lo = half + mel_chunk_word(il), x_lo = il >> 3;
 #else
         p_hi = half + ih, x_hi = ih >> 3;
         p_lo = half + il, x_lo = il >> 3;
@@ -111,9 +117,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     const uint32_t tw_off = 32u * (uint32_t)lane;  // byte offset of the lane's eight raw filterbank weights (LOUD / MID tiers)
     // bin lane + 64 e3 (+ 256) of the magnitude stage in the same order: word e_base + 32 e3 (+ 128)
 #if SR_MEL_CHUNKED
-    const int e_base = 256 * ((lane >> 2) & 1) + 4 * (lane >> 3) + (lane & 3);
+    const int e_base = mel_chunk_word(lane);  // bins lane + 64 e3 (+ 256): 8 e3 (+ 32) slots further on, bit 2 of the slot untouched
     constexpr int kEs = 32, kEh = 128;
-    const int c0 = 4 * lane, c1 = 256 + 4 * lane;
+    const int c0 = mel_chunk_word(8 * lane), c1 = mel_chunk_word(8 * lane + 4);
 #else
     const int e_base = lane;
     constexpr int kEs = 64, kEh = 256;
@@ -162,8 +168,8 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int i = lane + 64 * k;
-                // stored as the pass-1 output A >> 2 of the s16 sample (16-bit LDS store; the gather zero-extends)
-                if (i < kFrameLen) xw[i] = (uint16_t)window_sample(s_pp[k], mid, hamm_m[k]);
+                // stored as the pass-1 output A >> 2 of the s16 sample (the gather reads the low 16 bits, zero-extended)
+                if (i < kFrameLen) xw[i] = window_sample(s_pp[k], mid, hamm_m[k]);
             }
             if (fi + 1 < nf) {
                 const uint16_t *x = row + seg0 + (int)kHop * (int)(f0 + fi + 1);
@@ -222,9 +228,7 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                 // never read on this path: "defined" by an empty asm so that the quiet frame does not pay 16 register clears
                 asm volatile("" : "=v"(tw_e[0]), "=v"(tw_e[1]), "=v"(tw_o[0]), "=v"(tw_o[1]));
             }
-            // energies go to the wave's scratch in the CHUNKED order the filterbank reads them in: bin 8 l + k at word
-            // 256 (k >> 2) + 4 l + (k & 3), so that lane l's two 16-byte reads (and the prefix stores below) are lane-contiguous
-            // 16-byte chunks -- conflict-free; 8-word lane strides put two lanes of every service group on the same banks
+            // energies go to the wave's scratch in the chunked order the filterbank reads them in (mel_chunk_word)
             uint32_t *eb = buf + e_base;
             if (cheap) {
 #pragma unroll

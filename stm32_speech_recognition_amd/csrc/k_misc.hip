@@ -78,12 +78,12 @@ __global__ void k_math_diag(const uint32_t *in, uint32_t *out, uint32_t n, const
     if (i >= n) return;
     const uint32_t x = in[i];
     out[3 * i + 0] = log100_u32(x, log_thr);
-    // the exact routine and the bracketed fast path of the DTW kernel are reported through one word: the exact value,
-    // or a poison value if the fast path claims "safe" and disagrees (tests/exhaustive_math_sweep.py: all 2^32 inputs)
+    // the exact routine and the from-below root of the DTW kernel's step are reported through one word: the exact value,
+    // or a poison value if the from-below root is anything but the exact one or one less (tests/exhaustive_math_sweep.py: all
+    // 2^32 inputs)
     {
-        bool unsafe = false;
-        const uint32_t q = sqrt_floor_bracket(x, unsafe), e = cvt_u32(sqrt_rn_int((float)x));
-        out[3 * i + 1] = (unsafe || q == e) ? e : 0xDEAD0001u;
+        const uint32_t q = sqrt_floor_low(x), e = cvt_u32(sqrt_rn_int((float)x));
+        out[3 * i + 1] = (q == e || q + 1 == e) ? e : 0xDEAD0001u;
     }
     out[3 * i + 2] = cvt_u32(sqrt_rn_int((float)(int)(x & 0x7FFFFFFFu)) * 10.0f);
 }

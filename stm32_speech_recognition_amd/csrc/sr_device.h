@@ -117,6 +117,7 @@ struct DtwArgs {
     uint32_t cells_points;        // k_dtw_cells only: most band points of any pair of this store (dtw_cells_max_points; 0 = kernel not usable)
     uint32_t tpl_neg2_ok;         // k_dtw_quad only: every coefficient of the store lies in [-16383, 16384], so -2 * coefficient fits s16 (checked when the store is set)
     uint32_t cells_literal;       // k_dtw_cells only: development hook "cells_literal" -- every pair takes the literal fallback walk
+    uint32_t dev_cus, dev_lds_cu, dev_lds_wg;  // compute units / LDS bytes per CU / LDS bytes one workgroup may take on this device (sr_create); 0 = MI355X's 256 / 160 KiB / 160 KiB
 };
 
 // get_mdl (DTW.C:217-296): P independent pairs

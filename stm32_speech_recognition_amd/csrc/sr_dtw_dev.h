@@ -52,16 +52,17 @@ __device__ __forceinline__ uint32_t dis_from(uint32_t na, uint32_t nb, int dot)
     return cvt_u32(sqrt_rn_int((float)d));
 }
 
-// floor(sqrtf(f)) by bracketing: v_sqrt_f32 is within 1 ulp, so the correctly rounded root is s0 or one of its two
-// neighbours; when floor() of both neighbours agree the answer is known without the correction step.  `unsafe`
-// collects the (rare: ~1e-4 per value) cases that need sqrt_rn_int.  Validated for all 2^32 inputs by
-// tests/exhaustive_math_sweep.py through sr_math_diag.
-__device__ __forceinline__ uint32_t sqrt_floor_bracket(uint32_t d, bool &unsafe)
+// floor(sqrtf((float)d)) from BELOW: v_sqrt_f32 is within 1 ulp of the correctly rounded root r, so pred(s0) <= r and
+// floor(pred(s0)) is g = floor(r) or g - 1 (2 ulp < 1 for every u32 input) -- never above.  k_dtw_lds takes this value
+// and learns from its own tie threshold T(mn) (the first squared distance whose root is mn + 1, exact by table) whether it
+// is one short: d >= T(mn) <=> g = mn + 1.  Validated for all 2^32 inputs by tests/exhaustive_math_sweep.py through
+// sr_math_diag (the diagnostic poisons its output word if the value is ever anything but g or g - 1).
+__device__ __forceinline__ uint32_t sqrt_floor_low(uint32_t d)
 {
     const float s0 = __builtin_amdgcn_sqrtf((float)d);
-    const uint32_t hi = (uint32_t)__int_as_float(__float_as_int(s0) + 1);  // floor(succ(s0))
-    unsafe |= !(s0 > (float)hi);  // s0 > hi  <=>  pred(s0) >= hi  <=>  floor(pred(s0)) == hi as well
-    return hi;
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(__int_as_float(__float_as_int(s0) - 1)));  // NaN (d = 0) -> 0
+    return r;
 }
 // a - b, saturating at 0
 __device__ __forceinline__ uint32_t sub_sat(uint32_t a, uint32_t b)

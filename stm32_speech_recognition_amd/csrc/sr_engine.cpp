@@ -227,6 +227,14 @@ int sr_create(const sr_config *cfg, sr_engine **out)
     if (const int64_t gv = dev_hook(kHookMfccGrid)) {  // development hook: workgroups of the frame kernel
         if (gv > 0) h->mfcc_grid_cap = (uint32_t)gv;
     }
+    {  // what launch-shape decisions need to know about THIS device (a partitioned or CU-masked part is not 256 CUs)
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) h->n_cu = (uint32_t)v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v > 0) h->lds_per_cu = (uint32_t)v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+            h->lds_per_wg = std::max<uint32_t>((uint32_t)v, 64u * 1024u) > h->lds_per_cu ? h->lds_per_cu : std::max<uint32_t>((uint32_t)v, 64u * 1024u);
+        (void)hipGetLastError();
+    }
     build_tables(h->host, fe);
     warn_log_table();
     // one blob, 16-byte aligned sub-tables

@@ -88,6 +88,7 @@ struct sr_engine {
     sr_config cfg;
     int device = 0;
     uint32_t noise_len = 0, atap_frm = 0;
+    uint32_t n_cu = 256, lds_per_cu = 160 * 1024, lds_per_wg = 160 * 1024;  // of the engine's device (sr_create): launch-shape decisions use these, not MI355X's figures
     uint32_t mag_cheap_max = 0;  // kMagCheapMax once the device sweep at sr_create has confirmed the cheap magnitude form on this chip, else 0
     uint32_t mfcc_tile = 64, mfcc_tile_mid = 64, mfcc_tile_small = 64, mfcc_grid_cap = 0;  // frames per k_mfcc work item (batch form / the two forms for underfilled launches), resident workgroups
     uint32_t frame_len = 160, hop = 80;          // 160/80 reference, 320/160 extension, or the generic front end's framing
@@ -122,10 +123,14 @@ struct sr_engine {
     DevBuf<sr_vad_rec> s_vad2;
     DevBuf<uint32_t> s_pcnt;  // k_dtw_cells: finished-pair counters per utterance of a call, zero between launches (kPairCounters)
     // The counters are hidden per-engine state shared by every launch: two small calls in flight on DIFFERENT caller streams
-    // would both count in them.  They therefore belong to one caller stream (the first that uses them; internal chunk streams
-    // are forked from / joined to it, so its order covers them); a call on any other stream leaves the slot scan to k_argmin.
+    // would both count in them.  They therefore belong to one caller stream at a time (internal chunk streams are forked from /
+    // joined to it, so its order covers them); a call on any other stream leaves the slot scan to k_argmin -- unless the last
+    // launch that used the counters has COMPLETED (ev_cells, recorded behind every such launch): then nothing is in flight in
+    // them and the calling stream becomes the owner (round 6; before, the first stream kept them for the engine's lifetime,
+    // e.g. the internal stream of a first host-buffer call, or a stream the caller had destroyed since).
     hipStream_t cells_owner = nullptr;
     bool cells_owner_set = false;
+    hipEvent_t ev_cells = nullptr;
     // An asynchronous *_dev call that was handed no buffer for an intermediate uses the engine's scratch (s_vad, s_mfcc,
     // s_scores, s_vad2) on the CALLER's stream.  The event marks the end of the last such call; the host-buffer entry points,
     // which reuse the same scratch on internal or the null stream, order their stream behind it first (order_after_scratch_users).

@@ -183,13 +183,17 @@ __device__ __forceinline__ void load_tw32(const u32x4 *lds, int lane, uint32_t (
         f[4 * c + 3] = q.w;
     }
 }
-// pass-3 coefficients depend on (d0, d1) only: 4 x 32 words, read with lane-broadcast by d0 = lane & 3
+// pass-3 coefficients depend on (d0, d1) only: 4 x 32 words, read with lane-broadcast by d0 = lane & 3.  The four rows are
+// kTw3Row = 9 chunks apart, not 8: the lanes of a ds_read_b128 service group hold all four d0, and with rows of 32 words
+// d0 = 0 / 2 (and 1 / 3) fall on the same banks with different addresses -- every one of the loads was a 2-way conflict
+// (round 6: 32 of k_mfcc's 53 conflict cycles per frame, profiles/experiments/RESULTS.md)
+constexpr int kTw3Row = 9;
 __device__ __forceinline__ void load_tw32_d0(const u32x4 *lds, int d0, uint32_t (&k)[4][4][2])
 {
     uint32_t *f = &k[0][0][0];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const u32x4 q = lds[d0 * 8 + c];
+        const u32x4 q = lds[d0 * kTw3Row + c];
         f[4 * c] = q.x;
         f[4 * c + 1] = q.y;
         f[4 * c + 2] = q.z;
@@ -201,7 +205,10 @@ __device__ __forceinline__ void load_tw32_d0(const u32x4 *lds, int d0, uint32_t 
 // non-zero and every imaginary part is 0.  Pass 1 (.s:226-232) then degenerates exactly to
 // out[4*idx+k] = x[bitrev8(idx)] >> 2 (k = 0..3), so it is folded into the gather.
 // lane = d0 + 4*d3 + 16*d4 ; v[d1][d2] <-> j = d0 + 4*d1 + 16*d2 + 64*d3 + 256*d4.
-__device__ __forceinline__ void fft_front_real160(const uint16_t *xw, int lane, const LaneTw &tw, const u32x4 *tw3_lds,
+// xw: the windowed frame as one 32-bit word per sample (16-bit pattern in the low half, the high half is never read): 4-byte
+// stores of consecutive samples and the 2-byte reads below at word base + 16 m are both conflict-free; with two samples per
+// word the stores of lanes 2 m / 2 m + 1 went to one word
+__device__ __forceinline__ void fft_front_real160(const uint32_t *xw, int lane, const LaneTw &tw, const u32x4 *tw3_lds,
                                                   uint32_t (&v)[4][4])
 {
     const int d3 = (lane >> 2) & 3, d4 = lane >> 4;
@@ -209,7 +216,7 @@ __device__ __forceinline__ void fft_front_real160(const uint16_t *xw, int lane, 
     // bitrev8(j>>2) = base + 16*rev2(d2) + 64*rev2(d1); >= 160 <=> zero padding
     uint32_t y[10];
 #pragma unroll
-    for (int m = 0; m < 10; m++) y[m] = xw[base + 16 * m];  // already A >> 2 as a 16-bit pattern (pass 1, .s:147-148)
+    for (int m = 0; m < 10; m++) y[m] = *(const uint16_t *)(xw + base + 16 * m);  // already A >> 2 as a 16-bit pattern (pass 1, .s:147-148)
 #pragma unroll
     for (int d2 = 0; d2 < 4; d2++) {
         const int r2 = ((d2 & 1) << 1) | (d2 >> 1);

@@ -150,6 +150,9 @@ DtwArgs dtw_args(const sr_engine *h, const int16_t *d_mfcc, const sr_vad_rec *d_
     a.cells_points = h->cells_points;
     a.tpl_neg2_ok = h->tpl_staged_ok ? 1u : 0u;
     a.cells_literal = dev_hook(kHookCellsLiteral) != 0 ? 1u : 0u;
+    a.dev_cus = h->n_cu;
+    a.dev_lds_cu = h->lds_per_cu;
+    a.dev_lds_wg = h->lds_per_wg;
     return a;
 }
 
@@ -169,13 +172,14 @@ static uint64_t small_launch_pairs(const DtwArgs &a) { return (dtw_quad_fits(a) 
 // "round" is what the chip holds at once (workgroups per CU by LDS, at most 8, x 256 CUs).  The batch kernel's time is flat up
 // to ~400 000 pairs (126 us at the firmware's shapes), a round of the quad kernel takes a third of that, so the automatic mode
 // hands it launches of up to two rounds (profiles/r05_small_launch_sweep.json).
-static uint64_t quad_launch_pairs(const DtwArgs &a)
+static uint64_t quad_launch_pairs(const sr_engine *h, const DtwArgs &a)
 {
     uint32_t pu = 0, pk = 0;
     size_t lds = 0;
     if (!dtw_quad_pick(a, &pu, &pk, &lds)) return 0;
-    const uint64_t per_cu = std::min<uint64_t>(8, 128 / ((lds + 1279) / 1280));
-    return 2 * 256 * per_cu * pu * pk;
+    const uint64_t granules = (uint64_t)h->lds_per_cu / 1280;  // gfx950 hands out LDS in granules of 1 280 bytes (128 per CU on MI355X)
+    const uint64_t per_cu = std::min<uint64_t>(8, granules / ((lds + 1279) / 1280));
+    return 2 * (uint64_t)h->n_cu * per_cu * pu * pk;
 }
 // `owner` = the caller-level stream of the call (the counters belong to one caller stream, see sr_engine::cells_owner)
 bool launch_dtw_auto(sr_engine *h, DtwArgs &a, uint32_t b0, hipStream_t s, hipStream_t owner)
@@ -184,17 +188,26 @@ bool launch_dtw_auto(sr_engine *h, DtwArgs &a, uint32_t b0, hipStream_t s, hipSt
     if (h->small_launch != 1 && h->small_launch != 3 && dtw_cells_fits(a) && (h->small_launch == 2 || pairs <= small_launch_pairs(a))) {
         bool counters = a.results && (uint64_t)b0 + a.B <= kPairCounters;
         if (counters) {
+            if (!h->ev_cells && hipEventCreateWithFlags(&h->ev_cells, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                h->ev_cells = nullptr;
+            }
+            // another stream may take the counters over once the last launch that used them is done (nothing counts in them then)
+            if (h->cells_owner_set && h->cells_owner != owner && h->ev_cells && hipEventQuery(h->ev_cells) == hipSuccess)
+                h->cells_owner_set = false;
+            (void)hipGetLastError();  // hipErrorNotReady of the query is not an error of this call
             if (!h->cells_owner_set) {
                 h->cells_owner = owner;
                 h->cells_owner_set = true;
             }
-            counters = h->cells_owner == owner;
+            counters = h->cells_owner == owner && h->ev_cells != nullptr;
         }
         a.pair_count = counters ? h->s_pcnt.p + b0 : nullptr;
         launch_dtw_cells(a, s);
+        if (a.pair_count) (void)hipEventRecord(h->ev_cells, s);
         return a.pair_count != nullptr;
     }
-    if ((h->small_launch == 3 && dtw_quad_fits(a)) || (h->small_launch == 0 && pairs <= quad_launch_pairs(a))) {
+    if ((h->small_launch == 3 && dtw_quad_fits(a)) || (h->small_launch == 0 && pairs <= quad_launch_pairs(h, a))) {
         launch_dtw_quad(a, s);
         return false;
     }

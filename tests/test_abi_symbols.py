@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
 
 
 HOOKS = ("dtw_u", "dtw_tie_g", "dtw_kc", "mfcc_grid", "perturb_log_thr", "log_thr_from_host", "multi_allow_dup", "dtw_debug",
-         "cells_literal")
+         "cells_literal", "mag_cheap_off")
 
 
 def test_product_library_has_no_development_hooks():

@@ -1442,15 +1442,19 @@ def test_bench_plain_command_launches_its_own_ranks():
     assert abs(j["value"] - 8192 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
 
 
-def _check_multi_rank_line(j, n, B, launcher):
+def _check_multi_rank_line(j, n, B, launcher, exchange="scores"):
     assert j["n_gpus"] == n and j["steps"] == 2 and j["launcher"].startswith(launcher)
     assert j["config"]["batch_per_gpu"] == B and "all-gather" in j["config"]["parallelism"]
     assert abs(j["value"] - n * B * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
     assert j["top1_word_accuracy"] == 1.0
     x = j["exchange"]
-    assert x["ranks_in_communicator"] == n and x["allgather_bytes_per_rank_out"] == n * B * 100 * 4
+    # what one rank receives per step: the whole score matrix (north_star) or, --exchange results, 16 bytes per utterance
+    assert x["ranks_in_communicator"] == n and x["allgather_bytes_per_rank_out"] == n * B * (100 * 4 if exchange == "scores" else 16)
+    assert ("result records" in j["config"]["parallelism"]) == (exchange == "results")
     r = j["roofline"]  # an N = 8 line carries roofline, cpu_baseline, exchange and a parity flag
-    assert 0 < r["frac"] < 1 and 0 < r["timed_step_frac"] < 1 and "valu_frac" in r
+    assert 0 < r["frac"] < 1 and 0 < r["timed_step_frac"] < 1 and "valu_frac" in r and "valu_frac_vs_2cycle_peak" in r
+    if launcher == "ranks":
+        assert "exposed_allgather_ms" in x and "allgather_ms" in x
     cb = j["cpu_baseline"]
     assert cb["value"] > 0 and cb["gpu_results_identical_on_sample"] is True
     ps = cb["per_rank_sample"]
@@ -1471,6 +1475,11 @@ def test_bench_eight_ranks_dry_run():
     j, _ = _run_bench(["--gpus", "8", "--batch", "2048", "--steps", "2", "--warmup", "1", "--cpu-sample", "256"], hooks, timeout=1500)
     _check_multi_rank_line(j, 8, 2048, "ranks")
     assert len(j["exchange"]["step_ms_per_rank"]) == 8 and j["scaling"] == "weak"
+    # the cheaper exchange the driver can A/B against the default (round 6): gather the 16-byte result records instead of the
+    # score matrix; parity then reads argmin / distance of every rank's sample from the gathered records
+    j, _ = _run_bench(["--gpus", "8", "--batch", "2048", "--steps", "2", "--warmup", "1", "--cpu-sample", "256", "--exchange", "results"],
+                      hooks, timeout=1500)
+    _check_multi_rank_line(j, 8, 2048, "ranks", exchange="results")
     j, _ = _run_bench(["--gpus", "8", "--scaling", "strong", "--batch", "16384", "--steps", "2", "--warmup", "1", "--cpu-sample", "128"],
                       hooks, timeout=1500)
     _check_multi_rank_line(j, 8, 2048, "ranks")
@@ -1554,12 +1563,20 @@ def test_bench_other_configs_and_roofline_keys():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
     assert r["overlapped"]["launches_per_step"] >= 2 and r["overlapped"]["utterances_per_launch"] < 8192
     assert j["cpu_baseline"]["gpu_results_identical_on_sample"] is True
+    # the line says what the frame kernel saw: the generator's amplitude and the share of frames per magnitude / filterbank tier
+    ws = j["workload_stats"]
+    assert ws["gain"] == 1.0 and ws["quiet_frame_fraction"] > 0.9 and ws["frames_counted"] == 32 * 256
+    assert abs(ws["quiet_frame_fraction"] + ws["mid_frame_fraction"] + ws["loud_frame_fraction"] - 1) < 1e-9
+    assert j["config"]["gain"] == 1.0
     oc = j["other_configs"]
-    assert len(oc) == 3 and "configs[4] EXTENSION" in oc[1]["workload"] and "10 templates" in oc[0]["workload"]
-    for e in oc[:2]:
+    assert len(oc) == 4 and "configs[4] EXTENSION" in oc[2]["workload"] and "10 templates" in oc[1]["workload"]
+    loud = oc[0]  # the metric's configuration at the amplitudes SURVEY.md 8(d) specifies (scaled down here)
+    assert "SURVEY.md 8(d)" in loud["workload"] and "100 templates" in loud["workload"] and loud["workload_stats"]["gain"] == 2.4
+    assert loud["workload_stats"]["quiet_frame_fraction"] < 0.5 and loud["workload_stats"]["loud_frame_fraction"] > 0.1
+    for e in oc[:3]:
         assert e["value"] > 0 and e["parity_on_sample"]["identical"] is True and e["kernel_ms_isolated"]["mfcc"] > 0
         assert e["top1_word_accuracy"] == 1.0
-    dp = oc[2]  # the opt-in NON-REFERENCE full-DP scorer, timed alone
+    dp = oc[3]  # the opt-in NON-REFERENCE full-DP scorer, timed alone
     assert "NON-REFERENCE" in dp["workload"] and dp["kernel"] == "k_dtw_dp_band<8>" and dp["parity_on_sample"]["identical"] is True
     assert dp["pairs_per_s"] > 0 and 15000 < dp["cells_per_pair"] < 30000
     lat = j["latency"]  # one call of the drop-in symbols next to the reference's objects on one host core
@@ -2329,6 +2346,46 @@ def test_magnitude_cheap_form_exhaustive(eng119):
     assert out[0] == 0 and out[1] == 0xFFFFFFFF, out
     assert eng119.L.sr_mag_fast_sweep(eng119.h, C.c_uint32((1 << 24) - 1), _vp(out)) == 0
     assert out[0] > 0 and out[1] > 26843 * 2, out
+
+
+def test_magnitude_sweep_at_create_and_its_fallback():
+    """sr_create sweeps the cheap magnitude form over its whole range on the device the engine runs on and falls back to the
+    exactly corrected root for every frame if the chip's v_sqrt_f32 does not reproduce it (parity must not rest on
+    a property of one stepping that only the test suite checks).  Here: the product reports the bound 70 171 on this device;
+    an engine of the -DSR_TESTING build with the hook "mag_cheap_off" -- which makes sr_create behave as if the sweep had
+    failed -- reports 0 and still gives the same MFCC bytes on captures that cover all three tiers."""
+    from stm32_speech_recognition_amd import Engine
+    from stm32_speech_recognition_amd.engine import dev_hook
+    T, B = 64, 36
+    bank = synth.word_bank(8)
+    gains = np.repeat([0.6, 1.0, 2.4, 4.0], B // 4)
+    pcm = np.concatenate([synth.as_u16_numpy(synth.make_utterances([i % 8], [T], seed=70 + i, bank=bank, gain=float(g)))
+                          for i, g in enumerate(gains)])
+    e = Engine(max_frames=T + 8, device=0)
+    assert e.mag_cheap_bound() == 70171
+    dev_hook("mag_cheap_off", 1)
+    try:
+        et = Engine(max_frames=T + 8, device=0, testing=True)
+    finally:
+        dev_hook("mag_cheap_off", 0)
+    assert et.mag_cheap_bound() == 0
+    # MFCC rows through the stage-level call of both engines
+    v0 = e.vad(pcm)
+    v1 = et.vad(pcm)
+    assert np.array_equal(v0["seg"], v1["seg"]) and (v0["status"] == 0).all()
+    n0, f0 = e.mfcc(pcm, v0["seg"][:, 0], v0["seg"][:, 1], v0["mid_val"])
+    n1, f1 = et.mfcc(pcm, v1["seg"][:, 0], v1["seg"][:, 1], v1["mid_val"])
+    assert (n0 == T).all() and np.array_equal(n0, n1) and np.array_equal(f0, f1)
+    orc = ol.Oracle(max_frames=T + 8)
+    tiers = orc.frame_tiers(pcm)
+    assert min(tiers["quiet"], tiers["mid"], tiers["loud"]) > 0.05, tiers
+    for b in (0, B // 2, B - 1):
+        rc, a = orc.noise_atap(pcm[b])
+        seg = orc.vad(pcm[b], a)
+        n, m = orc.mfcc(pcm[b], seg[0], seg[1], a)
+        assert np.array_equal(f0[b, :n], m)
+    e.close()
+    et.close()
 
 
 def test_filterbank_fused_and_literal_forms_match_oracle():

@@ -377,29 +377,28 @@ def test_dtw_tie_threshold_table_is_exact(oracle):
     assert (np.diff(_root(oracle, xs)) >= 0).all()
 
 
-def test_dtw_bracket_fixup_predicate_is_exact(oracle):
-    """When floor(succ(v_sqrt_f32(d))) may be one too many, k_dtw_lds settles it with
-    g(d) < k  <=>  fmaf(-k, pred(k), (float)d) <= 0   (k - h, h = half an ulp below k, is where sqrtf rounds up to k).
-    The fused residual is evaluated here in float64, where k*pred(k) (48 bits) is exact and the subtraction keeps the
-    sign; compared with the C expression for every k <= 65535 on the d around k^2 and on random d."""
+def test_dtw_root_from_below_is_one_short_at_most(oracle):
+    """k_dtw_lds takes the root of a step as floor(pred(v_sqrt_f32((float)d))) (round 6) and learns from its own tie threshold
+    whether that is one short: d >= T(mn) <=> the root is mn + 1 (exact by the table test above).  What has to hold for it:
+    whatever 1-ulp-accurate value s0 the device's v_sqrt_f32 returns -- the correctly rounded root r or one of its two
+    neighbours -- floor(pred(s0)) is g = floor(r) or g - 1, never more and never less.  Modelled here with numpy's correctly
+    rounded float32 sqrt for all three candidates of s0, on the d around every perfect square and on random d; the device
+    itself is swept over all 2^32 inputs (tests/exhaustive_math_sweep.py through sr_math_diag)."""
     k = np.arange(1, 65536, dtype=np.int64)
-    kf = k.astype(np.float32)
-    pf = (kf.view(np.int32) - 1).view(np.float32)
     rng = np.random.default_rng(3)
-    for off in list(range(-40, 41, 1)) + [-600, -300, -129, 129, 300, 600]:
-        d = np.clip(k * k + off, 0, 2 ** 32 - 1)
-        f = d.astype(np.uint32).astype(np.float32)          # (float)d, round to nearest even like v_cvt_f32_u32 and C
-        test = (f.astype(np.float64) - kf.astype(np.float64) * pf.astype(np.float64)) <= 0
-        assert np.array_equal(test, _root(oracle, d) < k), off
-    d = rng.integers(0, 2 ** 32, 2_000_000, dtype=np.int64)
-    g = _root(oracle, d)
-    for kk in (g, g + 1):
-        sel = (kk >= 1) & (kk <= 65535)
-        kf = kk[sel].astype(np.float32)
-        pf = (kf.view(np.int32) - 1).view(np.float32)
-        f = d[sel].astype(np.uint32).astype(np.float32)
-        test = (f.astype(np.float64) - kf.astype(np.float64) * pf.astype(np.float64)) <= 0
-        assert np.array_equal(test, g[sel] < kk[sel])
+    ds = [np.clip(k * k + off, 0, 2 ** 32 - 1) for off in list(range(-40, 41)) + [-600, -300, -129, 129, 300, 600]]
+    ds.append(rng.integers(0, 2 ** 32, 2_000_000, dtype=np.int64))
+    for d in ds:
+        g = _root(oracle, d)
+        r = np.sqrt(d.astype(np.uint32).astype(np.float32))          # correctly rounded root of (float)d
+        assert np.array_equal(np.floor(r).astype(np.int64), g)
+        for step in (-1, 0, 1):                                      # s0 = pred(r), r, succ(r)
+            s0 = (r.view(np.int32) + step).view(np.float32)
+            p = (s0.view(np.int32) - 1).view(np.float32)             # pred(s0)
+            mn = np.floor(np.where(s0 > 0, p, 0)).astype(np.int64)
+            ok = (mn == g) | (mn == g - 1)
+            ok |= r == 0                                             # d = 0: the device converts NaN to 0 = g
+            assert ok.all(), (step, d[~ok][:5], mn[~ok][:5], g[~ok][:5])
 
 
 def store_to_templates(store, stride=4096, tmax=120, nc=12):

@@ -45,11 +45,24 @@ def _worker(rank, world, port, B_total, K, q):
     torch.distributed.destroy_process_group()
 
 
-def _pipeline_worker(rank, world, port, B_local, K, steps, q):
-    """the double-buffered exchange bench.py runs at N > 1: step i's gather is in flight while step i+1 computes"""
+def _fake_records(lo, hi, K):
+    """the 16-byte result records (best_tpl, min_dis, frm_num, status) the argmin kernel would write for _fake_scores"""
+    s = _fake_scores(lo, hi, K)
+    best, mn = du.argmin_first(torch.from_numpy(s.view(np.int32)))
+    r = np.zeros((hi - lo, 4), np.uint32)
+    r[:, 0], r[:, 1], r[:, 2] = best.numpy(), mn.numpy(), 256
+    return r
+
+
+def _pipeline_worker(rank, world, port, B_local, K, steps, q, kind="scores"):
+    """the double-buffered exchange bench.py runs at N > 1: step i's gather is in flight while step i+1 computes
+    (kind "scores": the u32 score matrix, bench.py's default; "results": the 16-byte result records, bench.py --exchange results)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     du.init_process_group("gloo")
+    make = _fake_scores if kind == "scores" else _fake_records
+    K, K_gen = (K, K) if kind == "scores" else (4, K)
+    _fs = lambda lo, hi, _k: make(lo, hi, K_gen)
     local = [torch.empty(B_local, K, dtype=torch.int32) for _ in range(2)]
     x = du.ScoreExchange(world, [torch.empty(world * B_local, K, dtype=torch.int32) for _ in range(2)])
     seen = []
@@ -59,7 +72,7 @@ def _pipeline_worker(rank, world, port, B_local, K, steps, q):
         if i >= 2:  # the buffer about to be overwritten holds step i-2's complete gather
             seen.append((i - 2, x.gathered[j].numpy().view(np.uint32).copy()))
         off = 1000 * i
-        local[j].copy_(torch.from_numpy(_fake_scores(off + rank * B_local, off + (rank + 1) * B_local, K).view(np.int32)))
+        local[j].copy_(torch.from_numpy(_fs(off + rank * B_local, off + (rank + 1) * B_local, K).view(np.int32)))
         x.launch(j, local[j])
     x.drain()
     for i in range(max(0, steps - 2), steps):
@@ -69,14 +82,16 @@ def _pipeline_worker(rank, world, port, B_local, K, steps, q):
     torch.distributed.destroy_process_group()
 
 
+@pytest.mark.parametrize("kind", ["scores", "results"])
 @pytest.mark.parametrize("world", [2, 8])
-def test_pipelined_exchange(world):
-    """the metric is quoted at 1/2/4/8 GPUs: the double-buffered exchange at world size 8 as well as 2"""
+def test_pipelined_exchange(world, kind):
+    """the metric is quoted at 1/2/4/8 GPUs: the double-buffered exchange at world size 8 as well as 2, gathering the score
+    matrix (north_star) or the 16-byte result records (bench.py --exchange results, SURVEY.md 8(e) names both)"""
     B_local, K, steps = 16, 6, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, B_local, K, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, B_local, K, steps, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=120) for _ in range(world)]
@@ -86,7 +101,11 @@ def test_pipelined_exchange(world):
     for rank, seen in outs:
         assert sorted(i for i, _ in seen) == list(range(steps))
         for i, g in seen:
-            assert np.array_equal(g, _fake_scores(1000 * i, 1000 * i + world * B_local, K)), (rank, i)
+            if kind == "scores":
+                assert np.array_equal(g, _fake_scores(1000 * i, 1000 * i + world * B_local, K)), (rank, i)
+            else:  # every rank's records, in global utterance order: (best_tpl, min_dis, frm_num, status) per utterance
+                want = np.concatenate([_fake_records(1000 * i + r * B_local, 1000 * i + (r + 1) * B_local, K) for r in range(world)])
+                assert g.shape == (world * B_local, 4) and np.array_equal(g, want), (rank, i)
 
 
 def test_shard_bounds_cover_everything():
