@@ -24,6 +24,6 @@ if [ -z "$XF" ]; then python profiles/summarize.py $OUT $1 $BATCH > /dev/null; e
 mkdir -p $R/gpurun_out/keep_$1
 cp profiles/$1_rocprof_summary.csv $OUT/bench_under_rocprof.json $R/gpurun_out/keep_$1/
 [ -z "$XF" ] && cp profiles/pmc_traffic.json profiles/pmc_valu.json $R/gpurun_out/keep_$1/
-case "$XF" in *"--workload ext"*) cp profiles/pmc_valu_ext.json $R/gpurun_out/keep_$1/;; *"--templates 10"*) cp profiles/pmc_valu_k10.json $R/gpurun_out/keep_$1/;; esac
+case "$XF" in *"--workload ext"*) cp profiles/pmc_valu_ext.json $R/gpurun_out/keep_$1/;; *"--templates 10"*) cp profiles/pmc_valu_k10.json $R/gpurun_out/keep_$1/;; *"--gain 2.4"*) cp profiles/pmc_valu_loud.json $R/gpurun_out/keep_$1/;; esac
 rm -rf $OUT
 ls $R/gpurun_out/keep_$1

@@ -130,9 +130,10 @@ def main():
         json.dump(j, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
     # VALU wave-instructions per utterance of the big kernels (whole-batch launch): bench.py prices a step against the VALU
     # issue ceiling with these.  One file per workload: pmc_valu.json (reference workload, B = 65536, K = 100),
-    # pmc_valu_ext.json (description holds "--workload ext": configs[4]), pmc_valu_k10.json ("--templates 10": configs[1])
+    # pmc_valu_ext.json (description holds "--workload ext": configs[4]), pmc_valu_k10.json ("--templates 10": configs[1]),
+    # pmc_valu_loud.json ("--gain 2.4": configs[2] at SURVEY.md 8(d)'s speech amplitudes)
     which = "pmc_valu.json" if not desc else "pmc_valu_ext.json" if "--workload ext" in desc else \
-        "pmc_valu_k10.json" if "--templates 10" in desc else None
+        "pmc_valu_k10.json" if "--templates 10" in desc else "pmc_valu_loud.json" if "--gain 2.4" in desc else None
     vj = {"source": f"profiles/{tag}_rocprof_summary.csv", "B": batch,
           "counter": "SQ_INSTS_VALU (wave-level instructions) and SQ_ACTIVE_INST_VALU (4-cycle issue slots: transcendentals count twice)"}
     for k in ("sr::k_vad", "sr::k_mfcc", "sr::k_mfcc_ext", "sr::k_dtw_lds", "sr::k_argmin"):
@@ -140,6 +141,8 @@ def main():
             vj[k.split("::")[1] + "_valu_insts_per_utt"] = vals[(k, "SQ_INSTS_VALU")] / float(batch)
         if (k, "SQ_ACTIVE_INST_VALU") in vals:
             vj[k.split("::")[1] + "_valu_slots_per_utt"] = vals[(k, "SQ_ACTIVE_INST_VALU")] / float(batch)
+    if "sr::k_mfcc" in set(kk for kk, _ in vals) and ("sr::k_mfcc", "SQ_INSTS_VALU") in vals:
+        vj["k_mfcc_valu_insts_per_frame"] = vals[("sr::k_mfcc", "SQ_INSTS_VALU")] / (batch * 256.0)
     if len(vj) > 3 and which and (desc or batch == 65536):
         vj["kernel_sources_sha"] = sources_sha(which)
         json.dump(vj, open(os.path.join(here, which), "w"), indent=1)

@@ -363,9 +363,6 @@ template <class F>  // F = Dtw12 / Dtw16: the row format
 __global__ void __launch_bounds__(1024) k_dtw_lds(const DtwLdsArgs a)
 {
     typedef typename F::Row Row;
-#ifdef SR_DTW_PRIO
-    __builtin_amdgcn_s_setprio(SR_DTW_PRIO);  // experiment (RESULTS.md round 6): issue priority over co-resident frame-kernel waves
-#endif
     extern __shared__ __attribute__((aligned(16))) u32x2 smem2[];  // 8-byte typed: rows are read as ds_read_b64
     const uint32_t U = a.U, R = a.d.max_frames, K = a.d.K;
     // LDS (all of it dynamic): [tie-threshold table, tie_g bytes][rows][norms][frame counts].  The table comes FIRST, at
