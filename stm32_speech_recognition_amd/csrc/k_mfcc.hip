@@ -40,7 +40,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
     __shared__ int s_dctS[kCoef * kMelPad];  // 32-bit: read with the wide LDS loads, no byte extraction
     __shared__ u32x4 s_tw3[kTw3Row * 4], s_tw5[8 * 64];  // pass-3 (per d0) / pass-5 (per lane) coefficients, shared by the waves
     __shared__ u32x4 s_tm[4 * 64];                 // filterbank multipliers of the lane's eight bins (both poly-lines)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (the wave index as a SCALAR: frame counts, loop bounds and the frame's sample pointer then live on the scalar unit --
+    // left in a VGPR they cost three vector instructions per frame for the next frame's load address and loop test)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *buf = smem + w * kWaveLdsWords;
     uint32_t *xw = buf;  // windowed frame, one word per sample: consumed by the pass-1 gather before the exchange overwrites it
     uint32_t *powb = buf + kXchgWords, *moff = powb + kFPW * kMelPad;
@@ -106,12 +108,14 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
         f_lo = (h == 0) ? 0 : (int)a.t.tri_cen[h - 1];
         const int f_hi = (h == kMel - 1) ? kBins : (int)a.t.tri_cen[h + 1];
         const int ih = f_hi - 1, il = f_lo ? f_lo - 1 : 0, half = (h & 1) ? kBins : 0;
+        // X holds INCLUSIVE lane sums: the bins below lane l's first bin sum to X[l - 1]; every edge looked up lies in lane >= 1
+        // (tri_cen[0] - 1 = 10), clamped so that an unused entry stays inside the array
 #if SR_MEL_CHUNKED
-        p_hi = half + mel_chunk_word(ih), x_hi = ih >> 3;
-        p_lo = half + mel_chunk_word(il), x_lo = il >> 3;
+        p_hi = half + mel_chunk_word(ih), x_hi = (ih >> 3) > 0 ? (ih >> 3) - 1 : 0;
+        p_lo = half + mel_chunk_word(il), x_lo = (il >> 3) > 0 ? (il >> 3) - 1 : 0;
 #else
-        p_hi = half + ih, x_hi = ih >> 3;
-        p_lo = half + il, x_lo = il >> 3;
+        p_hi = half + ih, x_hi = (ih >> 3) > 0 ? (ih >> 3) - 1 : 0;
+        p_lo = half + il, x_lo = (il >> 3) > 0 ? (il >> 3) - 1 : 0;
 #endif
     }
     const uint32_t tw_off = 32u * (uint32_t)lane;  // byte offset of the lane's eight raw filterbank weights (LOUD / MID tiers)
@@ -284,8 +288,8 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
                         }
                     }
                 }
-                xe = wave_scan_incl(se) - se;  // sum over the bins of the lanes below
-                xo = wave_scan_incl(so) - so;
+                xe = wave_scan_incl(se);  // sum over the bins of the lanes up to and including this one: a filter lane reads the
+                xo = wave_scan_incl(so);  // entry of the lane BELOW its bin's (never lane 0: the first filter edge is bin 10)
             }
             // (no ordering point is needed here: a lane overwrites only the eight energies it has read itself, every other
             // store below goes to words nobody reads before the next wave_sync)
@@ -308,7 +312,26 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 
         // ---- log (MFCC.C:165-170) and DCT (MFCC.C:173-183) for the wave's nf frames, all lanes busy
         // (the pad word of each row goes through the log as well: harmless, never read)
-        for (uint32_t t = lane; t < nf * kMelPad; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
+        // (round 6: all rounds' estimates first, then all threshold pairs in flight at once, then the corrections -- as a loop
+        // each round waited for its own pair of thresholds from the table in L2: seven serial round trips per 16 frames)
+        {
+            constexpr int kLogRounds = (kFPW * kMelPad + 63) / 64;
+            const uint32_t n_log = nf * kMelPad;
+            uint32_t nv[kLogRounds], mv[kLogRounds];
+            u32x2 tv[kLogRounds];
+#pragma unroll
+            for (int r = 0; r < kLogRounds; r++) {
+                const uint32_t t = lane + 64u * r;
+                nv[r] = powb[t];  // (rounds past n_log read the wave's own scratch behind the filterbank outputs: in bounds, unused)
+                mv[r] = log100_est(nv[r]);
+                tv[r] = *(const u32_pair_align4 *)((const char *)a.t.log_thr + 4u * mv[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < kLogRounds; r++) {
+                const uint32_t t = lane + 64u * r;
+                if (t < n_log) powb[t] = log100_fix(nv[r], mv[r], tv[r].x, tv[r].y) << 14;
+            }
+        }
         wave_sync();
         // output t = fi*12 + h of the wave's tile goes to out[(f0 + fi)*12 + h] = out_w[t]: consecutive lanes store
         // consecutive s16; fi = t / 12 by a 24-bit multiply (exact for t < 2^13), all index arithmetic in 32 bits

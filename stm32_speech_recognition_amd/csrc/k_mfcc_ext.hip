@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
     // window weights of the lane's 20 samples as fused multipliers (sr_tables.h hamm_fused_multiplier), layout A: chunk c of
     // gl at [c*16 + gl] = (even, odd) sample of pair 2c, (even, odd) sample of pair 2c + 1
     __shared__ u32x4 s_hm[5 * 16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar wave index, see k_mfcc
     const int g = lane >> 4, gl = lane & 15;
     uint32_t *xb = smem + w * kWaveWords;
     uint32_t *moff = xb + kXWords, *powb = moff + 2 * 16 * kGrp;
@@ -361,7 +361,24 @@ __global__ void __launch_bounds__(64 * ext::kWaves, 3) k_mfcc_ext(const MfccArgs
             }
             wave_sync();
         }
-        for (uint32_t t = lane; t < nf * kMelEPad; t += 64) powb[t] = log100_u32(powb[t], a.t.log_thr) << 14;
+        if (nf) {  // (round 6, as in k_mfcc: estimates of all rounds, all threshold pairs in flight at once, then the corrections)
+            constexpr int kLogRounds = (kFpw * kMelEPad + 63) / 64;
+            const uint32_t n_log = nf * kMelEPad;
+            uint32_t nv[kLogRounds], mv[kLogRounds];
+            u32x2 tv[kLogRounds];
+#pragma unroll
+            for (int r = 0; r < kLogRounds; r++) {
+                const uint32_t t = lane + 64u * r;
+                nv[r] = powb[t < n_log ? t : n_log - 1];  // (the filterbank outputs end the wave's scratch: stay inside it)
+                mv[r] = log100_est(nv[r]);
+                tv[r] = *(const u32_pair_align4 *)((const char *)a.t.log_thr + 4u * mv[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < kLogRounds; r++) {
+                const uint32_t t = lane + 64u * r;
+                if (t < n_log) powb[t] = log100_fix(nv[r], mv[r], tv[r].x, tv[r].y) << 14;
+            }
+        }
         wave_sync();
         {   // see k_mfcc: out[(f0 + fi)*12 + h] = out_w[t], 32-bit index arithmetic
             int16_t *out_w = out + (size_t)f0 * kCoef;

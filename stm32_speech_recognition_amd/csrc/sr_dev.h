@@ -137,6 +137,8 @@ __device__ __forceinline__ f32x2 sqrt_rn_int2(f32x2 f)
     return __builtin_elementwise_fma(r, h, s0);
 }
 typedef uint32_t u32_align2 __attribute__((aligned(2)));  // dword load at a 16-bit sample boundary
+typedef uint32_t u32x2_raw __attribute__((ext_vector_type(2)));
+typedef u32x2_raw u32_pair_align4 __attribute__((aligned(4)));  // two consecutive table words at any word boundary (one 8-byte load)
 typedef uint32_t u32x2_align2 __attribute__((ext_vector_type(2), aligned(2)));  // 8 bytes at a 16-bit sample boundary
 
 // ---- packed 16+16-bit helpers (VOP3P): one instruction works on the real and imaginary halves ----
@@ -246,12 +248,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 // UB cast of -inf gives 0) and the last step (its upper neighbour is the sentinel) -- and the two corrections are
 // compare + add/subtract-with-carry.  (The branching form the compiler made of the two-sided if cost two dependent
 // global loads with a wait each inside divergent control flow.)
+__device__ __forceinline__ uint32_t log100_est(uint32_t n)  // the clamped estimate m: thr[m], thr[m + 1] are the thresholds to look at
+{
+    return (uint32_t)(int)__builtin_amdgcn_fmed3f(__log2f((float)n) * 69.31471806f, 1.0f, (float)(kLogMax - 1));
+}
+__device__ __forceinline__ uint32_t log100_fix(uint32_t n, uint32_t m, uint32_t t0, uint32_t t1)
+{
+    return (uint32_t)((int)m - (int)(n < t0) + (int)(n >= t1));
+}
 __device__ __forceinline__ uint32_t log100_u32(uint32_t n, const uint32_t *__restrict__ thr)
 {
-    const float e = __builtin_amdgcn_fmed3f(__log2f((float)n) * 69.31471806f, 1.0f, (float)(kLogMax - 1));
-    const int m = (int)e;
-    const uint32_t t0 = thr[m], t1 = thr[m + 1];
-    return (uint32_t)(m - (int)(n < t0) + (int)(n >= t1));
+    const uint32_t m = log100_est(n);
+    return log100_fix(n, m, thr[m], thr[m + 1]);
 }
 
 }  // namespace sr

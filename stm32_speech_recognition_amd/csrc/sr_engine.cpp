@@ -249,6 +249,12 @@ int sr_create(const sr_config *cfg, sr_engine **out)
         tem[i] = mel_fused_multiplier(t.tri_even[i]);
         tom[i] = mel_fused_multiplier(t.tri_odd[i]);
     }
+    // k_mfcc looks the sums of the lanes BELOW a filter edge's lane up at index lane - 1 (inclusive lane sums): every edge it
+    // looks up must lie in lane >= 1, i.e. the first centre at bin 9 or later (11 for the reference's tables)
+    if (!h->generic && h->frame_len == (uint32_t)kFrameLen && (t.tri_cen.empty() || t.tri_cen[0] < 9)) {
+        delete h;
+        return fail(SR_ERR_BAD_CONFIG, "internal: first Mel centre below bin 9");
+    }
     std::vector<uint32_t> hpk(t.hamm.size() / 2);
     for (size_t i = 0; i < hpk.size(); i++) hpk[i] = (uint32_t)t.hamm[2 * i] | ((uint32_t)t.hamm[2 * i + 1] << 16);
     struct Part {
