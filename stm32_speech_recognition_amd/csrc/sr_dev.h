@@ -165,6 +165,14 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t c, uint32_t b)
     return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, c) +
                                                 __builtin_bit_cast(u16x2, b)));
 }
+// swap(a)*c + b per half, swap = the two halves of a exchanged: the exchange rides the instruction's operand selects
+// (op_sel / op_sel_hi of VOP3P: the low result takes a's HIGH half, the high result a's LOW half) instead of a v_alignbit_b32
+__device__ __forceinline__ uint32_t pk_mad_swap(uint32_t a, uint32_t c, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(c), "v"(b));
+    return r;
+}
 // (hi16(lo_src) , hi16(hi_src)) -> packed word: the ">>16" of a complex 32-bit pair in ONE v_perm_b32
 __device__ __forceinline__ uint32_t pk_hi16(int lo_src, int hi_src)
 {

@@ -70,13 +70,14 @@ __device__ __forceinline__ void r4_packed(uint32_t x0_in, int br, int bi, int sr
         B1 = pk_sub(A1, pk_s15(br, bi));
     }
     const uint32_t hC = pk_hi16(sr, si);
-    const uint32_t hD = CD_SAME ? __builtin_amdgcn_alignbit(hC, hC, 16) : pk_hi16(ti, tr);  // swapped: (D'i>>16, D'r>>16)
     x0 = pk_add(A1, hC);
-    x1 = pk_mad(hD, kPkPlusMinus, B1);
+    // D' with its halves swapped: (D'i>>16, D'r>>16).  CD_SAME: they are C''s own halves, exchanged by the multiply-add's operand
+    // selects (round 6; a v_alignbit_b32 each before: 8 instructions per frame in pass 2)
+    x1 = CD_SAME ? pk_mad_swap(hC, kPkPlusMinus, B1) : pk_mad(pk_hi16(ti, tr), kPkPlusMinus, B1);
     if (!HALF) {
-        const uint32_t pC = pk_s15(sr, si), pD = CD_SAME ? __builtin_amdgcn_alignbit(pC, pC, 16) : pk_s15(ti, tr);
+        const uint32_t pC = pk_s15(sr, si);
         x2 = pk_sub(x0, pC);
-        x3 = pk_mad(pD, kPkMinusPlus, x1);
+        x3 = CD_SAME ? pk_mad_swap(pC, kPkMinusPlus, x1) : pk_mad(pk_s15(ti, tr), kPkMinusPlus, x1);
     }
 }
 
