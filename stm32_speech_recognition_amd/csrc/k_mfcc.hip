@@ -172,8 +172,9 @@ __global__ void __launch_bounds__(64 * kMfccWaves, 4) k_mfcc(const MfccArgs a)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int i = lane + 64 * k;
-                // stored as the pass-1 output A >> 2 of the s16 sample (the gather reads the low 16 bits, zero-extended)
-                if (i < kFrameLen) xw[i] = window_sample(s_pp[k], mid, hamm_m[k]);
+                // stored as the pass-1 output A >> 2 of the s16 sample (the gather reads the low 16 bits, zero-extended); samples
+                // 0..63 (k = 0) are only ever A legs of pass 2 and are stored as that pass consumes them, >> 2 once more
+                if (i < kFrameLen) xw[i] = k == 0 ? window_sample<4>(s_pp[k], mid, hamm_m[k]) : window_sample<2>(s_pp[k], mid, hamm_m[k]);
             }
             if (fi + 1 < nf) {
                 const uint16_t *x = row + seg0 + (int)kHop * (int)(f0 + fi + 1);

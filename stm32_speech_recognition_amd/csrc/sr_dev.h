@@ -62,6 +62,10 @@ __device__ __forceinline__ int window_quotient(int c, int nq, int hm)
     const long long P = (long long)u * (long long)hm + (long long)(unsigned long long)(uint32_t)(u >> 31);
     return (int)(P >> 32);
 }
+// SH = 2: the pass-1 output A >> 2 of the sample; SH = 4: that shifted once more -- a sample that is only ever the A leg of a
+// pass-2 butterfly (rows 0..63 of the zero-padded frame, sr_fft_dev.h fft_front_real160) is stored as pass 2 consumes it,
+// (x >> 2) >> 2 = x >> 4 for arithmetic shifts, and pass 2 drops its own shift (round 6)
+template <int SH = 2>
 __device__ __forceinline__ uint32_t window_sample(uint32_t prev_cur, int mid, int hm)
 {
     const int nq = neg_preemph95((int)(prev_cur & 0xFFFFu) - mid);  // -((x[i-1] - mid)*95/100)
@@ -72,7 +76,7 @@ __device__ __forceinline__ uint32_t window_sample(uint32_t prev_cur, int mid, in
     // (s16)quotient >> 2 = bits 2..15 of the high dword, sign-extended: one v_bfe_i32 (stated as the instruction: left to the
     // compiler the 64-bit shift became v_alignbit_b32 + v_ashrrev_i32)
     int r;
-    asm("v_bfe_i32 %0, %1, 2, 14" : "=v"(r) : "v"((int)(P >> 32)));
+    asm("v_bfe_i32 %0, %1, %2, %3" : "=v"(r) : "v"((int)(P >> 32)), "n"(SH), "n"(16 - SH));
     return (uint32_t)r;
 }
 // full-rate 24-bit multiplies where the operands provably fit (quarter-rate v_mul_lo_u32 otherwise)

@@ -59,11 +59,12 @@ constexpr uint32_t kPkMinusPlus = 0x0001FFFFu;  // (-1, +1)
 
 // combine step on 32-bit products B, C' = C+D, D' = C-D and the packed sample A
 // CD_SAME: the D leg is zero, so C' = D' = C and the swapped D' halves are the C' halves rotated by 16 bits
-template <bool HALF, bool HAS_B, bool CD_SAME = false>
+// A_SHIFTED: x0_in already holds A >> 2 (k_mfcc stores the samples that are pass-2 A legs that way)
+template <bool HALF, bool HAS_B, bool CD_SAME = false, bool A_SHIFTED = false>
 __device__ __forceinline__ void r4_packed(uint32_t x0_in, int br, int bi, int sr, int si, int tr, int ti, uint32_t &x0,
                                           uint32_t &x1, uint32_t &x2, uint32_t &x3)
 {
-    const uint32_t a = pk_ashr(x0_in, 2);
+    const uint32_t a = A_SHIFTED ? x0_in : pk_ashr(x0_in, 2);
     uint32_t A1 = a, B1 = a;
     if (HAS_B) {
         A1 = pk_add(a, pk_hi16(br, bi));
@@ -217,7 +218,8 @@ __device__ __forceinline__ void fft_front_real160(const uint32_t *xw, int lane, 
     // bitrev8(j>>2) = base + 16*rev2(d2) + 64*rev2(d1); >= 160 <=> zero padding
     uint32_t y[10];
 #pragma unroll
-    for (int m = 0; m < 10; m++) y[m] = *(const uint16_t *)(xw + base + 16 * m);  // already A >> 2 as a 16-bit pattern (pass 1, .s:147-148)
+    // already A >> 2 as a 16-bit pattern (pass 1, .s:147-148); m < 4 = samples 0..63 = the A legs of pass 2, stored >> 2 once more
+    for (int m = 0; m < 10; m++) y[m] = *(const uint16_t *)(xw + base + 16 * m);
 #pragma unroll
     for (int d2 = 0; d2 < 4; d2++) {
         const int r2 = ((d2 & 1) << 1) | (d2 >> 1);
@@ -233,9 +235,9 @@ __device__ __forceinline__ void fft_front_real160(const uint32_t *xw, int lane, 
         if (d2 == 0 || d2 == 2) {
             int br, bi;
             cxmul(x1, tw.s2[0][0], tw.s2[0][1], br, bi);
-            r4_packed<false, true, true>(x0, br, bi, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
+            r4_packed<false, true, true, true>(x0, br, bi, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
         } else {
-            r4_packed<false, false, true>(x0, 0, 0, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
+            r4_packed<false, false, true, true>(x0, 0, 0, cr, ci, cr, ci, v[0][d2], v[1][d2], v[2][d2], v[3][d2]);
         }
     }
     // pass-3 coefficients (24 words per lane) are parked in LDS, shared by the workgroup's waves
