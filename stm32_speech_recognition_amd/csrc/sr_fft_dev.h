@@ -220,6 +220,9 @@ __device__ __forceinline__ void fft_front_real160(const uint32_t *xw, int lane, 
 #pragma unroll
     // already A >> 2 as a 16-bit pattern (pass 1, .s:147-148); m < 4 = samples 0..63 = the A legs of pass 2, stored >> 2 once more
     for (int m = 0; m < 10; m++) y[m] = *(const uint16_t *)(xw + base + 16 * m);
+    // (the A legs go into packed adds as they are: opaque, or the compiler re-zeroes halves that ds_read_u16 has just zero-extended)
+#pragma unroll
+    for (int m = 0; m < 4; m++) asm("" : "+v"(y[m]));
 #pragma unroll
     for (int d2 = 0; d2 < 4; d2++) {
         const int r2 = ((d2 & 1) << 1) | (d2 >> 1);
